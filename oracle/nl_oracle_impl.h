@@ -1,0 +1,264 @@
+/*
+ * oracle/nl_oracle_impl.h -- TEST INFRASTRUCTURE ONLY (see nl_oracle.c header).
+ *
+ * Type-generic body of the CPU restatement.  Included twice by nl_oracle.c with
+ *   REAL   = float | double      (the scalar type of the reference's `Vec`)
+ *   SUF(x) = x##_f32 | x##_f64
+ *
+ * Every function names the reference lines it restates (/root/reference/...).
+ * Arithmetic is written so that a C compiler with -ffp-contract=off evaluates it
+ * exactly like the reference's C++ does for Vec{REAL x,y,z}:
+ *   products/sums of REAL stay in REAL; the cut-off comparison promotes r2 to double
+ *   because search_length2_ is a double (neighlist_cpu.hpp:13,223).
+ */
+
+/* Grid parameters: ctor neighlist_cpu.hpp:380-395 and Initialize :408-411.
+ * ms_/ims_ live in a Vec, i.e. they are rounded to REAL (:12). */
+typedef struct {
+  int32_t m[3];
+  int64_t ncell;
+  REAL ms[3], ims[3];
+  double rc2;
+} SUF(grid);
+
+static int SUF(grid_init)(SUF(grid) * g, double rc, double Lx, double Ly, double Lz) {
+  const double L[3] = {Lx, Ly, Lz};
+  for (int d = 0; d < 3; d++) {
+    g->m[d] = (int32_t)(L[d] / rc);              /* :384-386 */
+    if (g->m[d] <= 0) return NLO_ERR_ARG;
+    g->ms[d] = (REAL)(L[d] / g->m[d]);           /* :389-391 (double quotient stored into Vec) */
+    g->ims[d] = (REAL)(1.0 / g->ms[d]);          /* :409-411 (1.0 is double; ms_ promoted) */
+  }
+  g->ncell = (int64_t)g->m[0] * g->m[1] * g->m[2]; /* :387 */
+  g->rc2 = rc * rc;                              /* :394 */
+  return NLO_OK;
+}
+
+/* ApplyPBC neighlist_cpu.hpp:61-66: a single +-m wrap, nothing more. */
+static void SUF(apply_pbc)(const SUF(grid) * g, int32_t* idx) {
+  for (int d = 0; d < 3; d++) {
+    if (idx[d] < 0) idx[d] += g->m[d];
+    if (idx[d] >= g->m[d]) idx[d] -= g->m[d];
+  }
+}
+
+/* GenHash(idx) neighlist_cpu.hpp:42-49. */
+static int64_t SUF(hash_idx)(const SUF(grid) * g, const int32_t* idx) {
+  return idx[0] + ((int64_t)idx[1] + (int64_t)idx[2] * g->m[1]) * g->m[0];
+}
+
+/* GenHash(q) neighlist_cpu.hpp:51-59.  Returns -1 where the reference would index
+ * out of bounds (coordinate further than one box length outside [0,L)). */
+static int64_t SUF(hash_pos)(const SUF(grid) * g, const REAL* q) {
+  int32_t idx[3];
+  for (int d = 0; d < 3; d++) {
+    const REAL t = q[d] * g->ims[d];
+    if (!(t > (REAL)-2147483000.0 && t < (REAL)2147483000.0)) return -1; /* NaN/overflow: UB in the reference */
+    idx[d] = (int32_t)t;
+  }
+  SUF(apply_pbc)(g, idx);
+  for (int d = 0; d < 3; d++)
+    if (idx[d] < 0 || idx[d] >= g->m[d]) return -1;
+  return SUF(hash_idx)(g, idx);
+}
+
+/* RegistInteractPair's accept rule neighlist_cpu.hpp:215-223:
+ * d = qj - qi per component, r2 = dx*dx + dy*dy + dz*dz (left to right), reject iff r2 > rc2(double). */
+static inline int SUF(accept)(const REAL* qi, const REAL* qj, double rc2) {
+  const REAL dx = qj[0] - qi[0];
+  const REAL dy = qj[1] - qi[1];
+  const REAL dz = qj[2] - qi[2];
+  const REAL r2 = dx * dx + dy * dy + dz * dz;
+  return !((double)r2 > rc2);
+}
+
+/*
+ * The whole build: MakeNeighList neighlist_cpu.hpp:417-435 with the
+ * WITHOUT_LOOP_FUSION pair loop (:239-270; the other two variants visit the same
+ * pair set in another order), then MakeNeighListForEachPtcl (:361-377).
+ *
+ * q: N particles, `stride` REALs apart, x,y,z first.
+ * Outputs (caller frees *sorted_list with nl_oracle_free):
+ *   number_of_partners[N]  half counts, counted on min(i,j)      (:235)
+ *   key_pointer[N+1]       exclusive prefix sum, 64-bit here      (:362-367)
+ *   *sorted_list[P]        partners in the reference's visit order (:369-372)
+ */
+int SUF(nl_oracle_build)(const REAL* q, int32_t stride, int64_t N, double rc, double Lx, double Ly,
+                         double Lz, int32_t* number_of_partners, int64_t* key_pointer,
+                         int32_t** sorted_list, int64_t* npairs) {
+  SUF(grid) g;
+  if (N < 0 || N > 2147483647LL || stride < 3) return NLO_ERR_ARG;
+  int rc_ = SUF(grid_init)(&g, rc, Lx, Ly, Lz);
+  if (rc_) return rc_;
+  const int64_t M = g.ncell;
+
+  int32_t* cell_of = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  int32_t* cell_n = (int32_t*)calloc((size_t)M, sizeof(int32_t));
+  int64_t* cell_beg = (int64_t*)malloc(sizeof(int64_t) * (size_t)(M + 1));
+  int64_t* cursor = (int64_t*)malloc(sizeof(int64_t) * (size_t)(M + 1));
+  int32_t* id_in_cell = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  int32_t* neigh = (int32_t*)malloc(sizeof(int32_t) * (size_t)M * 13);
+  int64_t cap = N * 64 + 1024, P = 0;
+  int32_t* key = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  int32_t* par = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  int ret = NLO_OK;
+  if (!cell_of || !cell_n || !cell_beg || !cursor || !id_in_cell || !neigh || !key || !par) {
+    ret = NLO_ERR_NOMEM;
+    goto done;
+  }
+
+  /* MakeNeighMeshId :107-132 -- the first 13 of the 27 offsets in (jz,jy,jx) order. */
+  {
+    int64_t c = 0;
+    for (int32_t iz = 0; iz < g.m[2]; iz++)
+      for (int32_t iy = 0; iy < g.m[1]; iy++)
+        for (int32_t ix = 0; ix < g.m[0]; ix++, c++) {
+          int k = 0;
+          for (int32_t jz = -1; jz < 2 && k < 13; jz++)
+            for (int32_t jy = -1; jy < 2 && k < 13; jy++)
+              for (int32_t jx = -1; jx < 2 && k < 13; jx++) {
+                int32_t idx[3] = {ix + jx, iy + jy, iz + jz};
+                SUF(apply_pbc)(&g, idx);
+                /* With a mesh of 1 along an axis one wrap is not enough (ix+jx = -1 -> 0 ok,
+                 * = 1 -> 0 ok), so every index is in range for m >= 1. */
+                neigh[13 * c + k++] = (int32_t)SUF(hash_idx)(&g, idx);
+              }
+        }
+  }
+
+  /* MakeMeshidOfPtcl :134-144 */
+  for (int64_t i = 0; i < N; i++) {
+    const int64_t h = SUF(hash_pos)(&g, q + (size_t)i * stride);
+    if (h < 0) {
+      ret = NLO_ERR_OUT_OF_BOX;
+      goto done;
+    }
+    cell_of[i] = (int32_t)h;
+    cell_n[h]++;
+  }
+  /* MakeNextDest :146-165 -- stable counting sort of ids by cell */
+  cell_beg[0] = cursor[0] = 0;
+  for (int64_t c = 0; c < M; c++) cell_beg[c + 1] = cursor[c + 1] = cell_beg[c] + cell_n[c];
+  for (int64_t i = 0; i < N; i++) id_in_cell[cursor[cell_of[i]]++] = (int32_t)i;
+
+  /* MakePairListNaive :239-270 */
+  memset(number_of_partners, 0, sizeof(int32_t) * (size_t)N);
+  for (int64_t c = 0; c < M; c++) {
+    const int64_t ib = cell_beg[c], ie = cell_beg[c + 1];
+    for (int64_t a = ib; a < ie; a++) {
+      const int32_t pi = id_in_cell[a];
+      const REAL* qi = q + (size_t)pi * stride;
+      for (int k = 0; k <= 13; k++) {
+        int64_t jb, je;
+        if (k < 13) { /* "for different mesh" :253-261 */
+          const int32_t jc = neigh[13 * c + k];
+          jb = cell_beg[jc];
+          je = cell_beg[jc + 1];
+        } else { /* "for same mesh" :264-267 */
+          jb = a + 1;
+          je = ie;
+        }
+        for (int64_t b = jb; b < je; b++) {
+          const int32_t pj = id_in_cell[b];
+          if (!SUF(accept)(qi, q + (size_t)pj * stride, g.rc2)) continue;
+          if (P == cap) {
+            cap *= 2;
+            int32_t* k2 = (int32_t*)realloc(key, sizeof(int32_t) * (size_t)cap);
+            int32_t* p2 = (int32_t*)realloc(par, sizeof(int32_t) * (size_t)cap);
+            if (k2) key = k2;
+            if (p2) par = p2;
+            if (!k2 || !p2) {
+              ret = NLO_ERR_NOMEM;
+              goto done;
+            }
+          }
+          const int32_t lo = pi < pj ? pi : pj, hi = pi < pj ? pj : pi; /* :225-232 */
+          key[P] = lo;
+          par[P] = hi;
+          number_of_partners[lo]++;
+          P++;
+        }
+      }
+    }
+  }
+
+  /* MakeNeighListForEachPtcl :361-377 */
+  {
+    int32_t* out = (int32_t*)malloc(sizeof(int32_t) * (size_t)(P > 0 ? P : 1));
+    int64_t* kp2 = (int64_t*)malloc(sizeof(int64_t) * (size_t)(N + 1));
+    if (!out || !kp2) {
+      free(out);
+      free(kp2);
+      ret = NLO_ERR_NOMEM;
+      goto done;
+    }
+    key_pointer[0] = kp2[0] = 0;
+    for (int64_t i = 0; i < N; i++) key_pointer[i + 1] = kp2[i + 1] = key_pointer[i] + number_of_partners[i];
+    for (int64_t p = 0; p < P; p++) out[kp2[key[p]]++] = par[p];
+    free(kp2);
+    *sorted_list = out;
+    *npairs = P;
+  }
+
+done:
+  free(cell_of);
+  free(cell_n);
+  free(cell_beg);
+  free(cursor);
+  free(id_in_cell);
+  free(neigh);
+  free(key);
+  free(par);
+  return ret;
+}
+
+/* Cell id of every particle, for unit-testing the device hash kernel
+ * (GenHash neighlist_cpu.hpp:51-59). cell[i] = -1 where the reference is out of bounds. */
+int SUF(nl_oracle_cells)(const REAL* q, int32_t stride, int64_t N, double rc, double Lx, double Ly,
+                         double Lz, int32_t* cell, int32_t* mesh3) {
+  SUF(grid) g;
+  int rc_ = SUF(grid_init)(&g, rc, Lx, Ly, Lz);
+  if (rc_) return rc_;
+  for (int d = 0; d < 3; d++) mesh3[d] = g.m[d];
+  for (int64_t i = 0; i < N; i++) cell[i] = (int32_t)SUF(hash_pos)(&g, q + (size_t)i * stride);
+  return NLO_OK;
+}
+
+/*
+ * Brute force half list, make_list.cpp:79-99 (+ make_sorted_list :101-118): for i, for j>i,
+ * reject iff dr2 > SEARCH_LENGTH2.  SEARCH_LENGTH2 there has type Dtype (= the position type,
+ * make_list.cpp:15,24); rc2_in_real selects that (1) or the class's double rc2 (0).
+ * Output is already canonical (ascending j per i).
+ */
+int SUF(nl_oracle_bruteforce)(const REAL* q, int32_t stride, int64_t N, double rc, int rc2_in_real,
+                              int32_t* number_of_partners, int64_t* key_pointer,
+                              int32_t** sorted_list, int64_t* npairs) {
+  const double rc2 = rc2_in_real ? (double)((REAL)rc * (REAL)rc) : rc * rc;
+  int64_t cap = N * 64 + 1024, P = 0;
+  int32_t* out = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  if (!out) return NLO_ERR_NOMEM;
+  key_pointer[0] = 0;
+  for (int64_t i = 0; i < N; i++) {
+    const REAL* qi = q + (size_t)i * stride;
+    int32_t n = 0;
+    for (int64_t j = i + 1; j < N; j++) {
+      if (!SUF(accept)(qi, q + (size_t)j * stride, rc2)) continue;
+      if (P == cap) {
+        cap *= 2;
+        int32_t* o2 = (int32_t*)realloc(out, sizeof(int32_t) * (size_t)cap);
+        if (!o2) {
+          free(out);
+          return NLO_ERR_NOMEM;
+        }
+        out = o2;
+      }
+      out[P++] = (int32_t)j;
+      n++;
+    }
+    number_of_partners[i] = n;
+    key_pointer[i + 1] = P;
+  }
+  *sorted_list = out;
+  *npairs = P;
+  return NLO_OK;
+}
