@@ -1,0 +1,169 @@
+/*
+ * nl_hip.h -- C ABI of libnl_hip.so: the MI355X (gfx950) Verlet neighbour-list builder.
+ *
+ * This is the drop-in boundary for the ONE hot path of kohnakagawa/md_neighbor_list:
+ *   cell hash -> sort by cell -> 27-cell pair search with cut-off test -> compaction into the pair list.
+ * The reference has no FFI layer; its boundary is the C++ class surface its two harnesses touch
+ * (SURVEY.md section 8b).  Every entry point below names the reference interface it replaces
+ * (file:line in the reference tree).  The header-only C++ shims include/neighlist_gpu.hpp (GPU harness
+ * surface: cuda_ptr<T>, NeighListGPU<Vec,Dtype>) and include/neighlist_cpu.hpp (CPU harness surface:
+ * NeighList<Vec>) are built on nothing but these functions.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an nl_status (0 = NL_OK) and never aborts or throws
+ *     (the reference aborts through checkCudaErrors / std::exit(1), device_util.cuh:41-54).
+ *   - a handle owns every device buffer it hands out; returned device pointers stay valid until the next
+ *     nl_make_list* / nl_initialize / nl_destroy on that handle (the reference's accessors return references to
+ *     members, neighlist_gpu.hpp:468-482).  The caller owns the position buffer.
+ *   - one handle per device per host thread; no global state (the reference keeps function-local statics,
+ *     neighlist_gpu.hpp:303, kernel_impl.cuh:222-226, and is not re-entrant).
+ *   - the result contract is the reference's SCALAR CPU class (neighlist_cpu.hpp): the half list
+ *     {(i,j): i<j, r2 <= rc2} with r2 = (dx*dx + dy*dy) + dz*dz evaluated without FMA in the position type and
+ *     compared against a double rc2 (neighlist_cpu.hpp:215-223), over the cell pairs that class visits.
+ */
+#ifndef NL_HIP_H
+#define NL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nl_handle_s* nl_handle_t;
+
+typedef enum nl_dtype {
+  NL_F32 = 0, /* Vec = float4-like  {x,y,z,w}, 16 B (make_list.cu:10-11) */
+  NL_F64 = 1  /* Vec = double4-like {x,y,z,w}, 32 B (make_list.cu:7-8)   */
+} nl_dtype;
+
+typedef enum nl_status {
+  NL_OK = 0,
+  NL_ERR_ARG = 1,            /* null/negative/inconsistent argument                                            */
+  NL_ERR_NOMEM = 2,          /* host or device allocation failed                                               */
+  NL_ERR_OUT_OF_BOX = 3,     /* a coordinate is NaN or more than one box length outside [0,L): the reference
+                                indexes out of bounds there (GenHash + one ApplyPBC wrap, neighlist_cpu.hpp:51-66) */
+  NL_ERR_CAPACITY = 4,       /* pair list larger than the capacity set for this handle (async builds only;
+                                the reference silently overruns MAX_PARTNERS*N, neighlist_cpu.hpp:37,76-78)    */
+  NL_ERR_HIP = 5,            /* a HIP runtime call failed; see nl_last_hip_error                               */
+  NL_ERR_STATE = 6,          /* call order violated (e.g. make_list before initialize, getter before a build)  */
+  NL_ERR_MESH = 7,           /* fewer than 3 cells along an axis: the reference visits cell pairs twice there
+                                and emits duplicate pairs; this library refuses such boxes                     */
+  NL_ERR_INDEX_OVERFLOW = 8, /* more than INT32_MAX pairs on one device with 32-bit key_pointer                */
+  NL_ERR_NO_DEVICE = 9,      /* no usable gfx950 device / wrong code object                                    */
+  NL_ERR_DOMAIN = 10         /* slab builds: a row particle outside the owned cells or a ghost inside them     */
+} nl_status;
+
+const char* nl_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------ lifecycle */
+
+/* Replaces the constructors NeighListGPU(rc,Lx,Ly,Lz) (neighlist_gpu.hpp:236-255) and NeighList(rc,Lx,Ly,Lz)
+ * (neighlist_cpu.hpp:380-395): mesh_size[d] = (int)(L_d / rc), ms = L/mesh_size, rc2 = rc*rc in double; ms and
+ * 1/ms are rounded to `dtype` exactly as the CPU class stores them in a Vec (neighlist_cpu.hpp:12,389-391,409-411).
+ * device_id < 0 selects the current HIP device. */
+int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, double Lz, int device_id);
+
+/* Replaces Initialize(N) (neighlist_gpu.hpp:268-287, neighlist_cpu.hpp:408-415): allocates every per-particle and
+ * per-cell buffer for up to n_max particles.  The pair-list capacity defaults to an estimate from the number
+ * density (1.3 x the ideal-gas half count + slack); see nl_set_capacity. Call once, or again to grow. */
+int nl_initialize(nl_handle_t h, int32_t n_max);
+
+/* Pair-list capacity in entries (int32 each).  A synchronous build grows the list by itself; an asynchronous
+ * one (sync = 0) cannot, and reports NL_ERR_CAPACITY at the next synchronising call instead of overrunning. */
+int nl_set_capacity(nl_handle_t h, int64_t max_pairs);
+
+int nl_destroy(nl_handle_t h);
+
+/* --------------------------------------------------------------------------------------------------- build */
+
+/* Replaces MakeNeighList(q, N, sync, tblock_size, smem_hei) (neighlist_gpu.hpp:289-466) and MakeNeighList(q, N)
+ * (neighlist_cpu.hpp:417-435).  q_dev: device pointer to n positions, `q_stride` scalars apart (4 for the
+ * float4/double4 Vec of make_list.cu, 3 for the {x,y,z} Vec of make_list.cpp:26-32).  Positions are read, never
+ * reordered (the reference's SortPtclData is commented out, neighlist_cpu.hpp:421).  stream: a hipStream_t or
+ * NULL for the handle's own stream.  sync != 0 waits for the build and returns its status; sync == 0 only
+ * enqueues (the reference's timing loop, make_list.cu:124-127) and errors surface at the next nl_synchronize /
+ * getter.  tblock_size and smem_hei of the reference select among its CUDA variants and have no counterpart. */
+int nl_make_list(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_t n, void* stream, int sync);
+
+/* Slab (domain-decomposed) build, SURVEY.md section 8e -- no reference counterpart (the reference is single GPU).
+ * The handle describes the GLOBAL box.  This rank owns the cell layers z in [z_lo, z_hi) of the global mesh and
+ * passes n_rows owned particles first, then n - n_rows ghost particles lying in the two periodic neighbour layers
+ * (z_lo-1 and z_hi, modulo mesh_z).  gid_dev: global particle ids (NULL = identity).  Rows are built for the
+ * owned particles only: row r holds the global ids j > gid[r] within the cut-off, so that the union over ranks
+ * is exactly the global half list.  z_lo = 0, z_hi = mesh_z, n_rows = n is the single-GPU build. */
+int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
+                      int32_t n, int32_t z_lo, int32_t z_hi, void* stream, int sync);
+
+/* Waits for the last enqueued build and returns its status (replaces the harness's
+ * checkCudaErrors(cudaDeviceSynchronize()), make_list.cu:128). */
+int nl_synchronize(nl_handle_t h);
+
+/* ------------------------------------------------------------------------------------------------- results */
+
+/* The CPU class's accessors (neighlist_cpu.hpp:437-463): key_pointer()[N+1], sorted_list()[P],
+ * number_of_partners()[N] (half counts, on min(i,j)), number_of_pairs() = P -- as DEVICE pointers.
+ * Partners of particle i are sorted_list[key_pointer[i] .. key_pointer[i+1]), in no particular order (the
+ * reference's order is its visit order; its own check sorts each segment first, make_list.cpp:120-128,211).
+ * Synchronises. Any out pointer may be NULL. */
+int nl_get_half_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_t** sorted_list_dev,
+                    const int32_t** number_of_partners_dev, int64_t* npairs);
+
+/* The GPU class's accessors neigh_list() / number_of_partners() (neighlist_gpu.hpp:468-482): the FULL list in
+ * the transposed layout list[k * row_stride + i], k < count[i], original particle ids, derived on the device
+ * from the half list of the last build.  Rows k >= count[i] hold -1 (the reference fills -1 once in Initialize,
+ * neighlist_gpu.hpp:271).  *max_partners receives the number of rows written (max_i count[i]).  Synchronises. */
+int nl_get_full_transposed(nl_handle_t h, const int32_t** list_dev, const int32_t** count_dev, int64_t* row_stride,
+                           int32_t* max_partners);
+
+/* number_of_pairs(): P, the half-pair count (neighlist_cpu.hpp:437-439).  The GPU class returns the sum of the
+ * full counts = 2P (neighlist_gpu.hpp:484-487); the C++ shim doubles it.  Synchronises. */
+int nl_number_of_pairs(nl_handle_t h, int64_t* npairs);
+
+/* ------------------------------------------------------------------------------------------- introspection */
+
+int nl_get_mesh(nl_handle_t h, int32_t mesh[3], int64_t* ncell);
+/* Cell-sorted state of the last build, for tests of the hash/sort stage (a3-a5 of SURVEY.md section 8):
+ * cell_start[ncell_local + 1]; sorted positions {x,y,z,id} (16 B for F32, 32 B {double x,y,z; int32 id,row}
+ * for F64); sorted_row[n] = input index of each sorted slot. */
+int nl_get_sorted(nl_handle_t h, const int32_t** cell_start_dev, const void** sorted_pos_dev,
+                  const int32_t** sorted_row_dev, int64_t* ncell_local);
+int nl_last_error(nl_handle_t h);     /* status of the last failed call on this handle */
+int nl_last_hip_error(nl_handle_t h); /* raw hipError_t behind the last NL_ERR_HIP */
+
+/* Per-kernel device time of one build, measured with HIP events on the stream the kernels were launched on.
+ * Runs `reps` builds of the given positions and returns average milliseconds per build for each stage
+ * (NL_STAGE_*) in ms[NL_NUM_STAGES]; ms[NL_STAGE_TOTAL] is first-launch to last-kernel-end. */
+enum {
+  NL_STAGE_HASH = 0,     /* cell hash + per-cell rank                       */
+  NL_STAGE_CELL_SCAN = 1,/* exclusive scan of the cell histogram            */
+  NL_STAGE_REORDER = 2,  /* physical reorder of positions into cell order   */
+  NL_STAGE_COUNT = 3,    /* pair search, counting pass                      */
+  NL_STAGE_ROW_SCAN = 4, /* exclusive scan of the counts -> key_pointer     */
+  NL_STAGE_FILL = 5,     /* pair search, list-filling pass                  */
+  NL_STAGE_TOTAL = 6,
+  NL_NUM_STAGES = 7
+};
+int nl_profile_stages(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_t n, int32_t reps,
+                      double ms[NL_NUM_STAGES]);
+/* Same, re-running the last successful build (single-device or slab) with the arguments it was given; the
+ * position / id buffers of that build must still be alive. */
+int nl_profile_last_build(nl_handle_t h, int32_t reps, double ms[NL_NUM_STAGES]);
+
+/* --------------------------------------------------------------------------------- buffers (cuda_ptr shim) */
+
+/* Back the reference's cuda_ptr<T> (cuda_ptr.cuh:11-112): a device buffer paired with a pinned host buffer. */
+int nl_buf_alloc(void** dev, void** host, size_t bytes);          /* allocate(), cuda_ptr.cuh:40-45        */
+int nl_buf_free(void* dev, void* host);                           /* deallocate(), cuda_ptr.cuh:107-111    */
+int nl_buf_h2d(void* dev, const void* host, size_t bytes);        /* host2dev(), cuda_ptr.cuh:47-53        */
+int nl_buf_d2h(void* host, const void* dev, size_t bytes);        /* dev2host(), cuda_ptr.cuh:62-69        */
+int nl_buf_fill32(void* dev, uint32_t pattern, size_t count);     /* set_val() device half, cuda_ptr.cuh:79-89 */
+int nl_buf_fill64(void* dev, uint64_t pattern, size_t count);
+int nl_device_synchronize(void);                                  /* make_list.cu:128                      */
+int nl_device_count(int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NL_HIP_H */

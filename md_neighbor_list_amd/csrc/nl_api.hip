@@ -1,0 +1,573 @@
+// nl_api.hip -- host side of libnl_hip.so: the C ABI of include/nl_hip.h over the kernels of nl_kernels.hpp.
+// No torch, no CUDA-compat layer: HIP runtime only.  Compiled for gfx950 with -ffp-contract=off.
+#include "../../include/nl_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "nl_kernels.hpp"
+
+using namespace nl;
+
+namespace {
+
+struct HostResult {  // pinned; written by an async D2H copy at the end of every build
+  uint32_t status;
+  uint32_t pad;
+  int64_t total;
+};
+
+}  // namespace
+
+struct nl_handle_s {
+  int dtype = NL_F32, device = 0;
+  double rc = 0, L[3] = {0, 0, 0}, rc2 = 0;
+  int32_t m[3] = {0, 0, 0};
+  int64_t ncell = 0;
+  float ims_f[3];
+  double ims_d[3];
+  float rc2_f = 0;
+
+  int32_t n_max = 0;
+  int64_t capacity = 0;
+  bool capacity_user = false;
+
+  // device buffers
+  int32_t* rank = nullptr;
+  void* sorted = nullptr;
+  int32_t* sorted_row = nullptr;
+  int32_t* count = nullptr;
+  int32_t* key_pointer = nullptr;
+  int32_t* progress = nullptr;
+  int32_t* cell_count = nullptr;  // [ncell] followed by the status word
+  int32_t* cell_start = nullptr;  // [ncell + 1]
+  int64_t* block_sum = nullptr;
+  int64_t* totals = nullptr;  // [0] = particles (cell scan), [1] = pairs (row scan)
+  uint32_t* status = nullptr;
+  int32_t* list = nullptr;
+  // transposed full list (compat output)
+  int32_t* t_list = nullptr;
+  int32_t* t_count = nullptr;
+  int32_t* t_cursor = nullptr;
+  int64_t t_rows_cap = 0;
+  int32_t t_max = 0;
+  bool t_valid = false;
+
+  HostResult* host = nullptr;
+  hipStream_t own_stream = nullptr;
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev[NL_NUM_STAGES + 1] = {};
+
+  // state of the last build
+  bool built = false, pending = false;
+  int32_t n = 0, n_rows = 0;
+  int64_t ncell_local = 0;
+  int last_error = NL_OK, last_hip = 0;
+  // arguments of the last build (to re-run the fill after growing the list)
+  int32_t b_mzl = 0, b_slab = 0, b_zlo = 0, b_stride = 4;
+  const void* b_q = nullptr;
+  const int32_t* b_gid = nullptr;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                         \
+  do {                                          \
+    hipError_t e_ = (call);                     \
+    if (e_ != hipSuccess) {                     \
+      (h)->last_hip = (int)e_;                  \
+      (h)->last_error = NL_ERR_HIP;             \
+      return NL_ERR_HIP;                        \
+    }                                           \
+  } while (0)
+
+int fail(nl_handle_t h, int code) {
+  if (h) h->last_error = code;
+  return code;
+}
+
+template <typename P> int dev_alloc(nl_handle_t h, P** p, size_t bytes) {
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    h->last_hip = (int)e;
+    return fail(h, e == hipErrorOutOfMemory ? NL_ERR_NOMEM : NL_ERR_HIP);
+  }
+  return NL_OK;
+}
+
+float floor_to_float(double v) {  // largest float <= v
+  float f = (float)v;
+  if ((double)f > v) f = std::nextafterf(f, -INFINITY);
+  return f;
+}
+
+int status_to_error(uint32_t st) {
+  if (st & ST_OUT_OF_BOX) return NL_ERR_OUT_OF_BOX;
+  if (st & ST_DOMAIN) return NL_ERR_DOMAIN;
+  if (st & ST_INDEX_OVERFLOW) return NL_ERR_INDEX_OVERFLOW;
+  if (st & ST_CAPACITY) return NL_ERR_CAPACITY;
+  return NL_OK;
+}
+
+template <typename T> Grid<T> make_grid(nl_handle_t h, int32_t n_rows, int32_t z_lo, int32_t mzl, int32_t slab) {
+  Grid<T> g;
+  for (int d = 0; d < 3; d++) {
+    g.ims[d] = sizeof(T) == 4 ? (T)h->ims_f[d] : (T)h->ims_d[d];
+    g.m[d] = h->m[d];
+  }
+  g.mzl = mzl;
+  g.slab = slab;
+  g.z_origin = slab ? ((z_lo - 1) % h->m[2] + h->m[2]) % h->m[2] : 0;
+  g.n_rows = n_rows;
+  return g;
+}
+
+// exclusive scan of in[n] into out[n+1]; grand total to total[0]
+int launch_scan(nl_handle_t h, const int32_t* in, int64_t n, int32_t* out, int64_t* total, hipStream_t s) {
+  const int32_t nb = (int32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, h->block_sum, nb, total);
+  hipLaunchKernelGGL(k_scan_down, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status);
+  return NL_OK;
+}
+
+template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
+  SweepArgs<T> a;
+  a.sorted = static_cast<const Pos<T>*>(h->sorted);
+  a.sorted_row = h->sorted_row;
+  a.cell_start = h->cell_start;
+  a.mx = h->m[0], a.my = h->m[1], a.mzl = h->b_mzl, a.slab = h->b_slab;
+  a.rc2 = sizeof(T) == 4 ? (T)h->rc2_f : (T)h->rc2;
+  a.count = h->count;
+  a.progress = h->progress;
+  a.key_pointer = h->key_pointer;
+  a.list = h->list;
+  a.total = h->totals + 1;
+  a.capacity = h->capacity;
+  a.status = h->status;
+  return a;
+}
+
+template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) {
+  const int32_t owned_layers = h->b_slab ? h->b_mzl - 2 : h->b_mzl;
+  const int32_t ncells_i = h->m[0] * h->m[1] * owned_layers;
+  const SweepArgs<T> a = sweep_args<T>(h);
+  if (mode == MODE_COUNT)
+    hipLaunchKernelGGL((k_sweep<T, MODE_COUNT>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_sweep<T, MODE_FILL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+}
+
+// Enqueues one whole build. ev != nullptr: records an event before every stage and one after the last.
+template <typename T>
+int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_t* gid, int32_t n_rows, int32_t n,
+                  int32_t z_lo, int32_t mzl, int32_t slab, hipStream_t s, hipEvent_t* ev) {
+  const Grid<T> g = make_grid<T>(h, n_rows, z_lo, mzl, slab);
+  const int64_t ncl = (int64_t)h->m[0] * h->m[1] * mzl;
+  h->ncell_local = ncl;
+  h->b_mzl = mzl, h->b_slab = slab, h->b_zlo = z_lo, h->b_stride = stride, h->b_q = q_dev, h->b_gid = gid;
+  const int32_t nbp = (n + 255) / 256;
+  const T* q = static_cast<const T*>(q_dev);
+
+  // cell histogram and the status word are one allocation: one memset node
+  HIPCHK(h, hipMemsetAsync(h->cell_count, 0, sizeof(int32_t) * (size_t)(h->ncell + 1), s));
+  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
+  if (n > 0) hipLaunchKernelGGL((k_hash<T>), dim3(nbp), dim3(256), 0, s, q, stride, n, g, h->cell_count, h->rank, h->status);
+  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_CELL_SCAN], s));
+  launch_scan(h, h->cell_count, ncl, h->cell_start, h->totals, s);
+  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_REORDER], s));
+  if (n > 0)
+    hipLaunchKernelGGL((k_reorder<T>), dim3(nbp), dim3(256), 0, s, q, stride, gid, n, g, h->cell_start, h->rank,
+                       static_cast<Pos<T>*>(h->sorted), h->sorted_row);
+  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_COUNT], s));
+  // rows of particles that were rejected by the hash (error paths) must still hold a defined count
+  HIPCHK(h, hipMemsetAsync(h->count, 0, sizeof(int32_t) * (size_t)(n_rows > 0 ? n_rows : 1), s));
+  launch_sweep<T>(h, MODE_COUNT, s);
+  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_ROW_SCAN], s));
+  launch_scan(h, h->count, n_rows, h->key_pointer, h->totals + 1, s);
+  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_FILL], s));
+  launch_sweep<T>(h, MODE_FILL, s);
+  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_TOTAL], s));
+  HIPCHK(h, hipGetLastError());
+  return NL_OK;
+}
+
+int enqueue_result_copy(nl_handle_t h, hipStream_t s) {
+  HIPCHK(h, hipMemcpyAsync(&h->host->status, h->status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(&h->host->total, h->totals + 1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  return NL_OK;
+}
+
+int dispatch_build(nl_handle_t h, const void* q, int32_t stride, const int32_t* gid, int32_t n_rows, int32_t n,
+                   int32_t z_lo, int32_t mzl, int32_t slab, hipStream_t s, hipEvent_t* ev) {
+  return h->dtype == NL_F32 ? enqueue_build<float>(h, q, stride, gid, n_rows, n, z_lo, mzl, slab, s, ev)
+                            : enqueue_build<double>(h, q, stride, gid, n_rows, n, z_lo, mzl, slab, s, ev);
+}
+
+int grow_list(nl_handle_t h, int64_t need) {
+  int64_t cap = std::max<int64_t>(need + need / 8 + 1024, h->capacity);
+  int rc = dev_alloc(h, &h->list, sizeof(int32_t) * (size_t)cap);
+  if (rc) {
+    h->capacity = 0;
+    return rc;
+  }
+  h->capacity = cap;
+  return NL_OK;
+}
+
+// Waits for the pending build; in a synchronous build an undersized list is grown and the fill pass re-run.
+int finish(nl_handle_t h, bool may_grow) {
+  if (!h->pending) return h->built ? NL_OK : fail(h, NL_ERR_STATE);
+  HIPCHK(h, hipStreamSynchronize(h->last_stream));
+  h->pending = false;
+  uint32_t st = h->host->status;
+  if ((st & ST_CAPACITY) && !(st & ~ST_CAPACITY) && may_grow) {
+    int rc = grow_list(h, h->host->total);
+    if (rc) return rc;
+    HIPCHK(h, hipMemsetAsync(h->status, 0, sizeof(uint32_t), h->last_stream));
+    if (h->dtype == NL_F32)
+      launch_sweep<float>(h, MODE_FILL, h->last_stream);
+    else
+      launch_sweep<double>(h, MODE_FILL, h->last_stream);
+    rc = enqueue_result_copy(h, h->last_stream);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->last_stream));
+    st = h->host->status;
+  }
+  const int err = status_to_error(st);
+  h->built = err == NL_OK;
+  if (err) return fail(h, err);
+  return NL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nl_status_string(int s) {
+  switch (s) {
+    case NL_OK: return "ok";
+    case NL_ERR_ARG: return "bad argument";
+    case NL_ERR_NOMEM: return "out of memory";
+    case NL_ERR_OUT_OF_BOX: return "particle more than one box length outside the box (or NaN)";
+    case NL_ERR_CAPACITY: return "pair list capacity exceeded";
+    case NL_ERR_HIP: return "HIP runtime error";
+    case NL_ERR_STATE: return "call order violated";
+    case NL_ERR_MESH: return "fewer than 3 cells along an axis";
+    case NL_ERR_INDEX_OVERFLOW: return "more than INT32_MAX pairs";
+    case NL_ERR_NO_DEVICE: return "no usable HIP device";
+    case NL_ERR_DOMAIN: return "particle outside the layers declared for this rank";
+    default: return "unknown status";
+  }
+}
+
+int nl_device_count(int* count) {
+  if (!count) return NL_ERR_ARG;
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  *count = c;
+  return NL_OK;
+}
+
+int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, double Lz, int device_id) {
+  if (!out) return NL_ERR_ARG;
+  *out = nullptr;
+  if ((dtype != NL_F32 && dtype != NL_F64) || !(rc > 0) || !(Lx > 0) || !(Ly > 0) || !(Lz > 0)) return NL_ERR_ARG;
+  const double L[3] = {Lx, Ly, Lz};
+  int32_t m[3];
+  for (int d = 0; d < 3; d++) {
+    const double r = L[d] / rc;
+    if (!(r < 2147483647.0)) return NL_ERR_ARG;
+    m[d] = (int32_t)r;  // neighlist_cpu.hpp:384-386
+    if (m[d] < 3) return NL_ERR_MESH;
+  }
+  if ((double)m[0] * m[1] * m[2] > 2.0e9) return NL_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NL_ERR_NO_DEVICE;
+  int dev = device_id;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return NL_ERR_NO_DEVICE;
+  if (dev >= ndev) return NL_ERR_ARG;
+  if (hipSetDevice(dev) != hipSuccess) return NL_ERR_NO_DEVICE;
+
+  nl_handle_t h = new (std::nothrow) nl_handle_s();
+  if (!h) return NL_ERR_NOMEM;
+  h->dtype = dtype, h->device = dev, h->rc = rc;
+  h->rc2 = rc * rc;  // neighlist_cpu.hpp:394 (double)
+  h->rc2_f = floor_to_float(h->rc2);
+  for (int d = 0; d < 3; d++) {
+    h->L[d] = L[d], h->m[d] = m[d];
+    // ms_ and ims_ live in a Vec of the position type (neighlist_cpu.hpp:12,389-391,409-411)
+    const float ms_f = (float)(L[d] / m[d]);
+    h->ims_f[d] = (float)(1.0 / (double)ms_f);
+    const double ms_d = L[d] / m[d];
+    h->ims_d[d] = 1.0 / ms_d;
+  }
+  h->ncell = (int64_t)m[0] * m[1] * m[2];
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&h->host), sizeof(HostResult), hipHostMallocDefault) != hipSuccess) {
+    nl_destroy(h);
+    return NL_ERR_HIP;
+  }
+  for (auto& e : h->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      nl_destroy(h);
+      return NL_ERR_HIP;
+    }
+  memset(h->host, 0, sizeof(HostResult));
+  *out = h;
+  return NL_OK;
+}
+
+int nl_destroy(nl_handle_t h) {
+  if (!h) return NL_ERR_ARG;
+  (void)hipSetDevice(h->device);
+  if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
+  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->count, h->key_pointer, h->progress, h->cell_count,
+                  h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (h->host) (void)hipHostFree(h->host);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return NL_OK;
+}
+
+int nl_initialize(nl_handle_t h, int32_t n_max) {
+  if (!h || n_max < 0) return fail(h, NL_ERR_ARG);
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->pending) {
+    int rc = finish(h, false);
+    (void)rc;
+  }
+  h->built = false;
+  const size_t n = (size_t)n_max;
+  const size_t pos_bytes = h->dtype == NL_F32 ? sizeof(Pos<float>) : sizeof(Pos<double>);
+  int rc;
+  if ((rc = dev_alloc(h, &h->rank, 4 * (n + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->sorted, pos_bytes * (n + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->sorted_row, 4 * (n + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->count, 4 * (n + 32)))) return rc;
+  if ((rc = dev_alloc(h, &h->key_pointer, 4 * (n + 32)))) return rc;
+  if ((rc = dev_alloc(h, &h->progress, 4 * (n + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->cell_start, 4 * ((size_t)h->ncell + 32)))) return rc;
+  const size_t nblk = std::max<size_t>(n, (size_t)h->ncell) / SCAN_BLOCK + 2;
+  if ((rc = dev_alloc(h, &h->block_sum, 8 * nblk))) return rc;
+  if ((rc = dev_alloc(h, &h->totals, 8 * 4))) return rc;
+  h->status = reinterpret_cast<uint32_t*>(h->cell_count + h->ncell);  // cleared by the same memset as the histogram
+  HIPCHK(h, hipMemset(h->totals, 0, 32));
+  HIPCHK(h, hipMemset(h->cell_count, 0, 4 * ((size_t)h->ncell + 16)));
+  h->n_max = n_max;
+  if (!h->capacity_user) {
+    // ideal-gas estimate of the half-pair count: N * rho * (2/3) pi rc^3, with 30 % head room
+    const double rho = (double)n_max / (h->L[0] * h->L[1] * h->L[2]);
+    const double per = rho * (2.0 / 3.0) * 3.14159265358979323846 * h->rc * h->rc * h->rc;
+    const int64_t want = (int64_t)((double)n_max * per * 1.3) + 64 * (int64_t)n_max + 4096;
+    if (want > h->capacity) {
+      if ((rc = dev_alloc(h, &h->list, 4 * (size_t)want))) return rc;
+      h->capacity = want;
+    }
+  }
+  h->t_valid = false;
+  return NL_OK;
+}
+
+int nl_set_capacity(nl_handle_t h, int64_t max_pairs) {
+  if (!h || max_pairs < 0) return fail(h, NL_ERR_ARG);
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->pending) (void)finish(h, false);
+  h->built = false;
+  int rc = dev_alloc(h, &h->list, 4 * (size_t)(max_pairs + 16));
+  if (rc) {
+    h->capacity = 0;
+    return rc;
+  }
+  h->capacity = max_pairs;
+  h->capacity_user = true;
+  return NL_OK;
+}
+
+int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
+                      int32_t n, int32_t z_lo, int32_t z_hi, void* stream, int sync) {
+  if (!h) return NL_ERR_ARG;
+  if (h->n_max <= 0 && n > 0) return fail(h, NL_ERR_STATE);
+  if (n < 0 || n_rows < 0 || n_rows > n || n > h->n_max || (q_stride != 3 && q_stride != 4) || (!q_dev && n > 0))
+    return fail(h, NL_ERR_ARG);
+  const int32_t mz = h->m[2];
+  if (z_lo < 0 || z_hi > mz || z_lo >= z_hi) return fail(h, NL_ERR_ARG);
+  const int32_t owned = z_hi - z_lo;
+  int32_t slab = 1, mzl = owned + 2;
+  if (owned == mz) {
+    slab = 0, mzl = mz;
+    if (n_rows != n) return fail(h, NL_ERR_ARG);
+  } else if (mz - owned < 2) {
+    return fail(h, NL_ERR_ARG);  // the two ghost layers would be the same layer
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->pending) {
+    // back-to-back asynchronous builds (the reference's timing loop): errors of the previous one are dropped,
+    // exactly like its results; stream order keeps the buffers consistent when the stream is the same.
+    if (h->last_stream != (stream ? (hipStream_t)stream : h->own_stream)) HIPCHK(h, hipStreamSynchronize(h->last_stream));
+    h->pending = false;
+  }
+  hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+  h->built = false;
+  h->t_valid = false;
+  h->n = n, h->n_rows = n_rows;
+  int rc = dispatch_build(h, q_dev, q_stride, gid_dev, n_rows, n, z_lo, mzl, slab, s, nullptr);
+  if (rc) return rc;
+  rc = enqueue_result_copy(h, s);
+  if (rc) return rc;
+  h->last_stream = s;
+  h->pending = true;
+  if (sync) return finish(h, true);
+  return NL_OK;
+}
+
+int nl_make_list(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_t n, void* stream, int sync) {
+  if (!h) return NL_ERR_ARG;
+  return nl_make_list_slab(h, q_dev, q_stride, nullptr, n, n, 0, h->m[2], stream, sync);
+}
+
+int nl_synchronize(nl_handle_t h) {
+  if (!h) return NL_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->pending && !h->built) return h->last_error ? h->last_error : fail(h, NL_ERR_STATE);
+  return finish(h, false);
+}
+
+int nl_get_half_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_t** sorted_list_dev,
+                    const int32_t** number_of_partners_dev, int64_t* npairs) {
+  if (!h) return NL_ERR_ARG;
+  int rc = nl_synchronize(h);
+  if (rc) return rc;
+  if (key_pointer_dev) *key_pointer_dev = h->key_pointer;
+  if (sorted_list_dev) *sorted_list_dev = h->list;
+  if (number_of_partners_dev) *number_of_partners_dev = h->count;
+  if (npairs) *npairs = h->host->total;
+  return NL_OK;
+}
+
+int nl_number_of_pairs(nl_handle_t h, int64_t* npairs) {
+  if (!h || !npairs) return fail(h, NL_ERR_ARG);
+  int rc = nl_synchronize(h);
+  if (rc) return rc;
+  *npairs = h->host->total;
+  return NL_OK;
+}
+
+int nl_get_mesh(nl_handle_t h, int32_t mesh[3], int64_t* ncell) {
+  if (!h) return NL_ERR_ARG;
+  if (mesh)
+    for (int d = 0; d < 3; d++) mesh[d] = h->m[d];
+  if (ncell) *ncell = h->ncell;
+  return NL_OK;
+}
+
+int nl_get_sorted(nl_handle_t h, const int32_t** cell_start_dev, const void** sorted_pos_dev,
+                  const int32_t** sorted_row_dev, int64_t* ncell_local) {
+  if (!h) return NL_ERR_ARG;
+  int rc = nl_synchronize(h);
+  if (rc) return rc;
+  if (cell_start_dev) *cell_start_dev = h->cell_start;
+  if (sorted_pos_dev) *sorted_pos_dev = h->sorted;
+  if (sorted_row_dev) *sorted_row_dev = h->sorted_row;
+  if (ncell_local) *ncell_local = h->ncell_local;
+  return NL_OK;
+}
+
+int nl_last_error(nl_handle_t h) { return h ? h->last_error : NL_ERR_ARG; }
+int nl_last_hip_error(nl_handle_t h) { return h ? h->last_hip : 0; }
+
+int nl_profile_last_build(nl_handle_t h, int32_t reps, double ms[NL_NUM_STAGES]) {
+  if (!h || !ms || reps <= 0) return fail(h, NL_ERR_ARG);
+  int rc = nl_synchronize(h);  // the build being profiled must have succeeded (buffers sized, list large enough)
+  if (rc) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  for (int k = 0; k < NL_NUM_STAGES; k++) ms[k] = 0;
+  hipStream_t s = h->own_stream;
+  HIPCHK(h, hipStreamSynchronize(h->last_stream));
+  for (int r = 0; r < reps; r++) {
+    rc = dispatch_build(h, h->b_q, h->b_stride, h->b_gid, h->n_rows, h->n, h->b_zlo, h->b_mzl, h->b_slab, s, h->ev);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(s));
+    for (int k = 0; k < NL_STAGE_TOTAL; k++) {
+      float t = 0;
+      HIPCHK(h, hipEventElapsedTime(&t, h->ev[k], h->ev[k + 1]));
+      ms[k] += t;
+    }
+    float t = 0;
+    HIPCHK(h, hipEventElapsedTime(&t, h->ev[0], h->ev[NL_STAGE_TOTAL]));
+    ms[NL_STAGE_TOTAL] += t;
+  }
+  for (int k = 0; k < NL_NUM_STAGES; k++) ms[k] /= reps;
+  rc = enqueue_result_copy(h, s);
+  if (rc) return rc;
+  h->last_stream = s;
+  h->pending = true;
+  return finish(h, false);
+}
+
+int nl_profile_stages(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_t n, int32_t reps,
+                      double ms[NL_NUM_STAGES]) {
+  if (!h || !ms || reps <= 0) return fail(h, NL_ERR_ARG);
+  int rc = nl_make_list(h, q_dev, q_stride, n, nullptr, 1);
+  if (rc) return rc;
+  return nl_profile_last_build(h, reps, ms);
+}
+
+/* ------------------------------------------------------------------ buffers */
+
+int nl_buf_alloc(void** dev, void** host, size_t bytes) {
+  if (!dev || !host) return NL_ERR_ARG;
+  *dev = *host = nullptr;
+  if (hipMalloc(dev, bytes ? bytes : 16) != hipSuccess) return NL_ERR_NOMEM;
+  if (hipHostMalloc(host, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+    (void)hipFree(*dev);
+    *dev = nullptr;
+    return NL_ERR_NOMEM;
+  }
+  return NL_OK;
+}
+int nl_buf_free(void* dev, void* host) {
+  int rc = NL_OK;
+  if (dev && hipFree(dev) != hipSuccess) rc = NL_ERR_HIP;
+  if (host && hipHostFree(host) != hipSuccess) rc = NL_ERR_HIP;
+  return rc;
+}
+int nl_buf_h2d(void* dev, const void* host, size_t bytes) {
+  return hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
+int nl_buf_d2h(void* host, const void* dev, size_t bytes) {
+  return hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost) == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
+int nl_buf_fill32(void* dev, uint32_t pattern, size_t count) {
+  if (hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(dev), (int)pattern, count) != hipSuccess) return NL_ERR_HIP;
+  return hipDeviceSynchronize() == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
+int nl_buf_fill64(void* dev, uint64_t pattern, size_t count) {
+  // two interleaved 32-bit patterns: fill as 32-bit words when both halves agree, else through a staging copy
+  const uint32_t lo = (uint32_t)pattern, hi = (uint32_t)(pattern >> 32);
+  if (lo == hi) return nl_buf_fill32(dev, lo, count * 2);
+  uint64_t* tmp = static_cast<uint64_t*>(malloc(sizeof(uint64_t) * (count ? count : 1)));
+  if (!tmp) return NL_ERR_NOMEM;
+  for (size_t i = 0; i < count; i++) tmp[i] = pattern;
+  const hipError_t e = hipMemcpy(dev, tmp, sizeof(uint64_t) * count, hipMemcpyHostToDevice);
+  free(tmp);
+  return e == hipSuccess ? NL_OK : NL_ERR_HIP;
+}
+int nl_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? NL_OK : NL_ERR_HIP; }
+
+}  // extern "C"
+
+#include "nl_transpose.inc"

@@ -1,0 +1,519 @@
+// nl_kernels.hpp -- hand-written CDNA4 (gfx950, wave64) kernels of the Verlet-list hot path.
+//
+// Pipeline of one build (reference lines in each kernel's comment):
+//   k_hash      cell hash + rank of each particle inside its cell        (a3)
+//   scan        exclusive scan of the cell histogram -> cell_start      (a4)
+//   k_reorder   positions physically moved into cell order, id carried  (a5: the reorder the reference left dead)
+//   k_sweep<COUNT>  27-cell pair search, counts only                    (a7)
+//   scan        exclusive scan of the counts -> key_pointer (CSR)       (a9)
+//   k_sweep<FILL>   27-cell pair search, wave-ballot compaction into the final CSR rows (a7+a8+a9)
+//
+// Arithmetic contract (bit-exact pair set vs the scalar CPU class): d = qj - qi per component,
+// r2 = (dx*dx + dy*dy) + dz*dz with separately rounded multiplies and adds -- this TU is compiled with
+// -ffp-contract=off and uses the explicit __f*_rn forms -- and a pair is kept unless r2 > rc2
+// (neighlist_cpu.hpp:219-223).  No MFMA: nothing here is a contraction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nl {
+
+constexpr int WAVE = 64;
+
+// bits of the device status word
+enum : uint32_t { ST_OUT_OF_BOX = 1u, ST_CAPACITY = 2u, ST_DOMAIN = 4u, ST_INDEX_OVERFLOW = 8u };
+
+// One cell-sorted particle. gid = the id written into neighbour rows and used for the i<j half-list rule.
+template <typename T> struct Pos;
+template <> struct alignas(16) Pos<float> {
+  float x, y, z;
+  int32_t gid;
+};
+template <> struct alignas(32) Pos<double> {
+  double x, y, z;
+  int32_t gid;
+  int32_t row;
+};
+
+template <typename T> struct Grid {
+  T ims[3];          // 1/ms rounded to T (neighlist_cpu.hpp:409-411)
+  int32_t m[3];      // global mesh (neighlist_cpu.hpp:384-386)
+  int32_t mzl;       // z layers held locally: m[2], or owned + 2 ghost layers for a slab
+  int32_t z_origin;  // global z layer of local layer 0
+  int32_t slab;      // 0: periodic wrap in z, every cell owned; 1: layers 0 and mzl-1 are ghosts
+  int32_t n_rows;    // particles [0, n_rows) are owned (get rows), [n_rows, n) are ghosts
+};
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+
+// GenHash(q) + ApplyPBC, neighlist_cpu.hpp:51-66: idx = (int32)(q * ims) truncated, one +-m wrap, then
+// idx.x + (idx.y + idx.z*my)*mx -- here with the z index taken relative to the local slab.
+// Returns -1 where the reference would index out of bounds, -2 for a particle outside this rank's layers.
+template <typename T>
+__device__ __forceinline__ int32_t local_cell(const Grid<T>& g, T x, T y, T z, int32_t* lz_out) {
+  const T t[3] = {mul_rn(x, g.ims[0]), mul_rn(y, g.ims[1]), mul_rn(z, g.ims[2])};
+  int32_t idx[3];
+  bool bad = false;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    if (!(t[d] > (T)-2147483000.0 && t[d] < (T)2147483000.0)) bad = true;  // NaN / overflow: UB in the reference
+    int32_t v = (int32_t)t[d];
+    if (v < 0) v += g.m[d];
+    if (v >= g.m[d]) v -= g.m[d];
+    if (v < 0 || v >= g.m[d]) bad = true;
+    idx[d] = v;
+  }
+  if (bad) return -1;
+  int32_t lz = idx[2] - g.z_origin;
+  if (lz < 0) lz += g.m[2];
+  if (lz >= g.mzl) return -2;
+  *lz_out = lz;
+  return idx[0] + (idx[1] + lz * g.m[1]) * g.m[0];
+}
+
+template <typename T>
+__device__ __forceinline__ void load_xyz(const T* __restrict__ q, int32_t stride, int32_t i, T& x, T& y, T& z) {
+  const T* p = q + (size_t)i * stride;
+  if (stride == 4) {
+    if constexpr (sizeof(T) == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      x = v.x, y = v.y, z = v.z;
+    } else {
+      const double2 a = *reinterpret_cast<const double2*>(p);
+      x = a.x, y = a.y, z = p[2];
+    }
+  } else {
+    x = p[0], y = p[1], z = p[2];
+  }
+}
+
+// a3: make_mesh (neighlist_gpu.hpp:26-41) / MakeMeshidOfPtcl (neighlist_cpu.hpp:134-144).
+// One thread per particle; the returning atomic on the cell histogram is the particle's rank in its cell.
+template <typename T>
+__global__ void __launch_bounds__(256) k_hash(const T* __restrict__ q, int32_t stride, int32_t n, Grid<T> g,
+                                               int32_t* __restrict__ cell_count, int32_t* __restrict__ rank,
+                                               uint32_t* __restrict__ status) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T x, y, z;
+  load_xyz(q, stride, i, x, y, z);
+  int32_t lz = 0;
+  const int32_t c = local_cell(g, x, y, z, &lz);
+  if (c < 0) {
+    atomicOr(status, c == -1 ? ST_OUT_OF_BOX : ST_DOMAIN);
+    rank[i] = -1;
+    return;
+  }
+  if (g.slab) {
+    const bool in_owned_layer = lz >= 1 && lz < g.mzl - 1;
+    if (in_owned_layer != (i < g.n_rows)) atomicOr(status, ST_DOMAIN);
+  }
+  rank[i] = atomicAdd(&cell_count[c], 1);
+}
+
+// a5: the physical reorder (dead code in the reference: CopyGather neighlist_gpu.hpp:144-151,
+// SortPtclData neighlist_cpu.hpp:176-180).  sorted[cell_start[c] + rank] = {x, y, z, id}.
+template <typename T>
+__global__ void __launch_bounds__(256) k_reorder(const T* __restrict__ q, int32_t stride,
+                                                  const int32_t* __restrict__ gid, int32_t n, Grid<T> g,
+                                                  const int32_t* __restrict__ cell_start,
+                                                  const int32_t* __restrict__ rank, Pos<T>* __restrict__ sorted,
+                                                  int32_t* __restrict__ sorted_row) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = rank[i];
+  if (r < 0) return;
+  T x, y, z;
+  load_xyz(q, stride, i, x, y, z);
+  int32_t lz = 0;
+  const int32_t c = local_cell(g, x, y, z, &lz);
+  const int32_t dst = cell_start[c] + r;
+  Pos<T> p;
+  p.x = x, p.y = y, p.z = z;
+  p.gid = gid ? gid[i] : i;
+  if constexpr (sizeof(T) == 8) p.row = i;
+  sorted[dst] = p;
+  sorted_row[dst] = i;
+}
+
+// ---------------------------------------------------------------------------------------------- scans
+// Exclusive scan of int32 counts (a4: thrust reduce_by_key + inclusive_scan neighlist_gpu.hpp:153-175 /
+// MakeNextDest neighlist_cpu.hpp:146-152; a9: MakeNeighListForEachPtcl neighlist_cpu.hpp:361-367).
+// Three small kernels: per-block sums, a one-block scan of those sums (64-bit), per-block scan + offset.
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;  // per thread, loaded as 4 x int4
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ int32_t wave_incl_scan(int32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const int32_t u = __shfl_up(v, d, WAVE);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ int64_t wave_incl_scan64(int64_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const int64_t u = __shfl_up(v, d, WAVE);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
+
+__device__ __forceinline__ void load_items(const int32_t* __restrict__ in, int64_t n, int64_t base, int32_t* v) {
+  if (base + SCAN_ITEMS <= n) {
+    const int4* p = reinterpret_cast<const int4*>(in + base);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS / 4; k++) {
+      const int4 a = p[k];
+      v[4 * k] = a.x, v[4 * k + 1] = a.y, v[4 * k + 2] = a.z, v[4 * k + 3] = a.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) v[k] = base + k < n ? in[base + k] : 0;
+  }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const int32_t* __restrict__ in, int64_t n,
+                                                               int64_t* __restrict__ block_sum) {
+  __shared__ int32_t wsum[SCAN_THREADS / WAVE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int32_t v[SCAN_ITEMS];
+  load_items(in, n, (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_ITEMS, v);
+  int32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, WAVE);
+  if (lane == 0) wsum[w] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t t = 0;
+    for (int k = 0; k < SCAN_THREADS / WAVE; k++) t += wsum[k];
+    block_sum[blockIdx.x] = t;
+  }
+}
+
+// One block: exclusive scan of nb block sums in place; the grand total goes to total[0].
+__global__ void __launch_bounds__(1024) k_scan_spine(int64_t* __restrict__ block_sum, int32_t nb,
+                                                      int64_t* __restrict__ total) {
+  __shared__ int64_t wsum[16];
+  __shared__ int64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int32_t base = 0; base < nb; base += 1024) {
+    const int32_t i = base + tid;
+    const int64_t x = i < nb ? block_sum[i] : 0;
+    int64_t inc = wave_incl_scan64(x, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int k = 0; k < w; k++) woff += wsum[k];
+    const int64_t carry = carry_s;
+    if (i < nb) block_sum[i] = carry + woff + inc - x;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (tid == 0) total[0] = carry_s;
+}
+
+// out[i] = exclusive prefix (int32); out[n] = total.  Flags ST_INDEX_OVERFLOW when the total exceeds INT32_MAX.
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __restrict__ in, int64_t n,
+                                                             const int64_t* __restrict__ block_off,
+                                                             const int64_t* __restrict__ total,
+                                                             int32_t* __restrict__ out,
+                                                             uint32_t* __restrict__ status) {
+  __shared__ int32_t wsum[SCAN_THREADS / WAVE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_ITEMS;
+  int32_t v[SCAN_ITEMS];
+  load_items(in, n, base, v);
+  int32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
+  const int32_t inc = wave_incl_scan(s, lane);
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int32_t woff = 0;
+  for (int k = 0; k < w; k++) woff += wsum[k];
+  int32_t run = (int32_t)block_off[blockIdx.x] + woff + inc - s;
+  if (base + SCAN_ITEMS <= n) {
+    int4* p = reinterpret_cast<int4*>(out + base);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS / 4; k++) {
+      int4 a;
+      a.x = run, run += v[4 * k];
+      a.y = run, run += v[4 * k + 1];
+      a.z = run, run += v[4 * k + 2];
+      a.w = run, run += v[4 * k + 3];
+      p[k] = a;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+      if (base + k < n) out[base + k] = run;
+      run += v[k];
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    const int64_t t = total[0];
+    out[n] = (int32_t)t;
+    if (t > 2147483647LL) atomicOr(status, ST_INDEX_OVERFLOW);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- sweep
+// a7 + a8 + a9: the pair search.  One workgroup per i-cell.  The particles of the 27 neighbour cells
+// (9 contiguous x-runs of the cell-sorted array, periodic wrap as MakeNeighMeshId neighlist_gpu.hpp:125-142 /
+// ApplyPBC neighlist_cpu.hpp:61-66) are staged back-to-back in LDS, so every 64-lane j-tile is dense.
+// Each wave then takes groups of up to G i-particles of the cell into SGPRs and walks the tiles:
+// lanes own j, i is wave-uniform, the cut-off mask comes out of v_cmp as a 64-bit SGPR pair (the wave64
+// counterpart of the reference's __ballot/__popc append, kernel_impl.cuh:272-280), and
+//   COUNT: the row count is advanced by s_bcnt1 of the mask,
+//   FILL : accepted j ids are written at key_pointer[row] + count + mbcnt(mask), i.e. straight into the final
+//          CSR row (no staging row + transpose as in kernel_impl.cuh:218-239).
+// Half-list rule: the pair is kept in the row of the smaller id (RegistInteractPair neighlist_cpu.hpp:225-236),
+// so lane j is accepted only if gid_j > gid_i; that also drops j == i.
+enum { MODE_COUNT = 0, MODE_FILL = 1 };
+
+template <typename T> struct SweepArgs {
+  const Pos<T>* __restrict__ sorted;
+  const int32_t* __restrict__ sorted_row;
+  const int32_t* __restrict__ cell_start;
+  int32_t mx, my, mzl, slab;
+  T rc2;                          // largest T value <= rc*rc in double, so !(r2 > rc2) == !((double)r2 > rc2_double)
+  int32_t* __restrict__ count;    // [n_rows] number_of_partners (COUNT writes, FILL reads nothing from it)
+  int32_t* __restrict__ progress; // [n_rows] scratch, only touched when a stencil needs more than one LDS batch
+  const int32_t* __restrict__ key_pointer;
+  int32_t* __restrict__ list;
+  const int64_t* __restrict__ total;
+  int64_t capacity;
+  uint32_t* __restrict__ status;
+};
+
+template <typename T> struct SweepCfg;
+template <> struct SweepCfg<float> { static constexpr int CAP = 1536; };   // 24 KB of LDS
+template <> struct SweepCfg<double> { static constexpr int CAP = 1024; };  // 32 KB of LDS
+
+constexpr int SWEEP_WAVES = 2;
+constexpr int SWEEP_G = 8;
+constexpr int NSEG = 18;
+
+// One group of GC (compile-time, 1..8) i-particles against the nj staged j-particles.
+// pi_l / base_l: lane k < GC holds i-particle k and the list offset of its row.  Returns, in lane k, the number
+// of accepted partners of i-particle k.  All per-i state is wave-uniform (SGPRs): position, id, running count.
+template <typename T, int MODE, int GC>
+__device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos<T>* tile, int32_t nj,
+                                                int32_t ntiles, int lane, const Pos<T>& pi_l, int32_t base_l) {
+  T xi[GC], yi[GC], zi[GC];
+  int32_t gi[GC], cnt[GC];
+  uint32_t base[GC];
+#pragma unroll
+  for (int k = 0; k < GC; k++) {
+    if constexpr (sizeof(T) == 4) {
+      xi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, pi_l.x), k));
+      yi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, pi_l.y), k));
+      zi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, pi_l.z), k));
+    } else {
+      xi[k] = __shfl(pi_l.x, k, WAVE);
+      yi[k] = __shfl(pi_l.y, k, WAVE);
+      zi[k] = __shfl(pi_l.z, k, WAVE);
+    }
+    gi[k] = __builtin_amdgcn_readlane(pi_l.gid, k);
+    base[k] = (uint32_t)__builtin_amdgcn_readlane(base_l, k);
+    cnt[k] = 0;
+  }
+
+  Pos<T> cur = tile[lane];
+  if (lane >= nj) cur.gid = INT32_MIN;  // tail lanes can never satisfy gid_j > gid_i
+  for (int32_t t = 0; t < ntiles; t++) {
+    Pos<T> nxt = cur;
+    if (t + 1 < ntiles) {
+      const int32_t jn = (t + 1) * WAVE + lane;
+      nxt = tile[jn];
+      if (jn >= nj) nxt.gid = INT32_MIN;
+    }
+#pragma unroll
+    for (int k = 0; k < GC; k++) {
+      const T dx = sub_rn(cur.x, xi[k]), dy = sub_rn(cur.y, yi[k]), dz = sub_rn(cur.z, zi[k]);
+      const T r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+      // two direct compares -> two SGPR masks -> s_and: no VALU spent on forming the ballot
+      const bool in_range = !(r2 > a.rc2), upper = cur.gid > gi[k];
+      const uint64_t mask = __builtin_amdgcn_ballot_w64(in_range) & __builtin_amdgcn_ballot_w64(upper);
+      if (MODE == MODE_FILL) {
+        if (in_range && upper) {
+          const uint32_t pre =
+              __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+          // uniform 64-bit base + 32-bit byte offset (global_store saddr form); the host keeps capacity < 2^30
+          const uint32_t boff = (base[k] + (uint32_t)cnt[k] + pre) << 2;
+          *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + boff) = cur.gid;
+        }
+      }
+      cnt[k] += __popcll(mask);
+    }
+    cur = nxt;
+  }
+  int32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < GC; k++) mine = lane == k ? cnt[k] : mine;
+  return mine;
+}
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
+  constexpr int CAP = SweepCfg<T>::CAP;
+  constexpr int NT = SWEEP_WAVES * WAVE;
+  constexpr int G = SWEEP_G;
+  static_assert(G == 8, "search_group dispatch covers group sizes 1..8");
+  __shared__ Pos<T> tile[CAP];
+
+  if (MODE == MODE_FILL) {
+    if (a.total[0] > a.capacity) {  // uniform: every workgroup leaves, nothing is written out of bounds
+      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
+      return;
+    }
+  }
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware cell order: blocks b, b+8, b+16.. share an XCD (and its L2), so give each XCD a contiguous
+  // range of cells (a z-slab of the box) instead of every 8th cell.
+  int32_t w;
+  {
+    const int32_t nb = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nb >> 3, r = nb & 7;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int32_t cx = w % a.mx, cy = (w / a.mx) % a.my, cz = w / (a.mx * a.my) + (a.slab ? 1 : 0);
+  const int32_t c = cx + (cy + cz * a.my) * a.mx;
+  const int32_t ibeg = a.cell_start[c], ni = a.cell_start[c + 1] - ibeg;
+  if (ni == 0) return;
+
+  // Segment table, one segment per lane (lanes >= 18 hold empty segments): 9 (dz,dy) rows x 2 x-parts.
+  int32_t seg_src = 0, seg_len = 0;
+  if (lane < NSEG) {
+    const int32_t s = lane >> 1, part = lane & 1, dz = s / 3 - 1, dy = s % 3 - 1;
+    int32_t y = cy + dy, z = cz + dz;
+    if (y < 0) y += a.my;
+    if (y >= a.my) y -= a.my;
+    if (!a.slab) {
+      if (z < 0) z += a.mzl;
+      if (z >= a.mzl) z -= a.mzl;
+    }
+    int32_t x0, x1;  // cells [x0, x1) of that row
+    if (cx == 0) {
+      x0 = part ? 0 : a.mx - 1, x1 = part ? 2 : a.mx;
+    } else if (cx == a.mx - 1) {
+      x0 = part ? 0 : a.mx - 2, x1 = part ? 1 : a.mx;
+    } else {
+      x0 = cx - 1, x1 = part ? cx - 1 : cx + 2;
+    }
+    const int32_t rowbase = (y + z * a.my) * a.mx;
+    seg_src = a.cell_start[rowbase + x0];
+    seg_len = a.cell_start[rowbase + x1] - seg_src;
+  }
+  const int32_t seg_off = wave_incl_scan(seg_len, lane) - seg_len;  // exclusive offsets in the staged stream
+  const int32_t total_j = __builtin_amdgcn_readlane(seg_off + seg_len, NSEG - 1);
+  const int32_t nbatch = (total_j + CAP - 1) / CAP;
+
+  // i-groups: `rounds` groups per wave, sized so that both waves get the same number of groups.
+  const int32_t rounds = (ni + SWEEP_WAVES * G - 1) / (SWEEP_WAVES * G);
+  const int32_t ngroups = rounds * SWEEP_WAVES;
+  const int32_t gsize = (ni + ngroups - 1) / ngroups;
+
+  for (int32_t batch = 0; batch < nbatch; batch++) {
+    const int32_t win0 = batch * CAP;
+    const int32_t nj = min(total_j - win0, CAP);
+    if (batch) __syncthreads();  // everyone is done reading the previous batch
+    // ---- stage: copy the stream window [win0, win0 + nj) into LDS, 6 segments' loads in flight at a time.
+    // Loads are unconditional (clamped to a valid slot) so that they issue back to back; only the LDS write
+    // is predicated.
+#pragma unroll
+    for (int s0 = 0; s0 < NSEG; s0 += 6) {
+      Pos<T> v0, v1, v2, v3, v4, v5;
+      int32_t d0, d1, d2, d3, d4, d5;
+#define NL_STAGE_LOAD(u, v, d)                                                          \
+  {                                                                                     \
+    const int32_t src = __builtin_amdgcn_readlane(seg_src, s0 + u);                     \
+    const int32_t len = __builtin_amdgcn_readlane(seg_len, s0 + u);                     \
+    const int32_t off = __builtin_amdgcn_readlane(seg_off, s0 + u);                     \
+    const int32_t dd = off + tid - win0;                                                \
+    const bool ok = tid < len && (uint32_t)dd < (uint32_t)CAP;                          \
+    d = ok ? dd : -1;                                                                   \
+    v = a.sorted[ok ? src + tid : ibeg];                                                \
+  }
+      NL_STAGE_LOAD(0, v0, d0)
+      NL_STAGE_LOAD(1, v1, d1)
+      NL_STAGE_LOAD(2, v2, d2)
+      NL_STAGE_LOAD(3, v3, d3)
+      NL_STAGE_LOAD(4, v4, d4)
+      NL_STAGE_LOAD(5, v5, d5)
+#undef NL_STAGE_LOAD
+      if (d0 >= 0) tile[d0] = v0;
+      if (d1 >= 0) tile[d1] = v1;
+      if (d2 >= 0) tile[d2] = v2;
+      if (d3 >= 0) tile[d3] = v3;
+      if (d4 >= 0) tile[d4] = v4;
+      if (d5 >= 0) tile[d5] = v5;
+    }
+    // long segments (more than NT particles): the rest, one stride at a time
+    for (int s = 0; s < NSEG; s++) {
+      const int32_t len = __builtin_amdgcn_readlane(seg_len, s);
+      if (len <= NT) continue;
+      const int32_t src = __builtin_amdgcn_readlane(seg_src, s);
+      const int32_t off = __builtin_amdgcn_readlane(seg_off, s);
+      for (int32_t k = tid + NT; k < len; k += NT) {
+        const int32_t d = off + k - win0;
+        if ((uint32_t)d < (uint32_t)CAP) tile[d] = a.sorted[src + k];
+      }
+    }
+    __syncthreads();
+
+    // ---- search: this wave's groups against every tile of the batch
+    const int32_t ntiles = (nj + WAVE - 1) / WAVE;
+    for (int32_t g = wave; g < ngroups; g += SWEEP_WAVES) {
+      const int32_t i0 = g * gsize;
+      const int32_t gcount = min(gsize, ni - i0);  // wave-uniform; may be <= 0 for the last groups
+      if (gcount <= 0) break;
+      // lane k < gcount holds i-particle k of the group
+      Pos<T> pi_l;
+      pi_l.x = 0, pi_l.y = 0, pi_l.z = 0, pi_l.gid = 0;
+      int32_t row_l = 0, base_l = 0;
+      if (lane < gcount) {
+        pi_l = a.sorted[ibeg + i0 + lane];
+        row_l = a.sorted_row[ibeg + i0 + lane];
+        if (MODE == MODE_FILL) base_l = a.key_pointer[row_l];
+        if (batch) base_l += a.progress[row_l];  // entries already produced by earlier batches
+      }
+      int32_t mine;  // lane k < gcount: hits of i-particle k in this batch
+      switch (gcount) {
+        case 1: mine = search_group<T, MODE, 1>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+        case 2: mine = search_group<T, MODE, 2>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+        case 3: mine = search_group<T, MODE, 3>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+        case 4: mine = search_group<T, MODE, 4>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+        case 5: mine = search_group<T, MODE, 5>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+        case 6: mine = search_group<T, MODE, 6>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+        case 7: mine = search_group<T, MODE, 7>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+        default: mine = search_group<T, MODE, 8>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+      }
+      if (lane < gcount) {
+        if (nbatch > 1) {
+          const int32_t before = batch ? a.progress[row_l] : 0;
+          mine += before;
+          a.progress[row_l] = mine;
+        }
+        if (MODE == MODE_COUNT && batch == nbatch - 1) a.count[row_l] = mine;
+      }
+    }
+  }
+}
+
+}  // namespace nl

@@ -1,0 +1,202 @@
+"""Python mirror of the reference's builder classes, over the C ABI of libnl_hip.so.
+
+``NeighListGPU`` keeps the call surface of the reference's ``NeighListGPU<Vec,Dtype>`` (neighlist_gpu.hpp:43-488:
+ctor, Initialize, MakeNeighList, neigh_list, number_of_partners, number_of_pairs) and adds the accessors of the
+scalar CPU class ``NeighList<Vec>`` (neighlist_cpu.hpp:437-463: key_pointer, sorted_list, half counts), because the
+CPU class's half CSR is the native output of the HIP path and the contract it is checked against.
+
+torch is plumbing only here: device memory for positions/results and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import NLError, check  # noqa: F401
+
+
+class _DevView:
+    """A borrowed device buffer exposed through __cuda_array_interface__ (zero copy into torch)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(int(s) for s in shape),
+            "typestr": typestr,
+            "data": (int(ptr), False),
+            "version": 2,
+            "strides": None,
+        }
+        self._owner = owner  # keeps the handle alive
+
+
+def _as_tensor(ptr, shape, typestr, owner, device):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    if n == 0 or not ptr:
+        dt = {"<i4": torch.int32, "<f4": torch.float32, "<f8": torch.float64}[typestr]
+        return torch.empty(tuple(int(s) for s in shape), dtype=dt, device=device)
+    return torch.as_tensor(_DevView(ptr, shape, typestr, owner), device=device)
+
+
+class NeighListGPU:
+    """Verlet neighbour-list builder on one MI355X.
+
+    Parameters follow neighlist_gpu.hpp:236-255: ``search_length`` (cut-off rc) and the box edges.  ``dtype``
+    plays the role of the reference's compile-time ``Dtype``/``Vec`` choice (make_list.cu:6-12).
+    """
+
+    def __init__(self, search_length, Lx, Ly, Lz, dtype=torch.float32, device=None):
+        if dtype not in (torch.float32, torch.float64):
+            raise TypeError("dtype must be torch.float32 or torch.float64")
+        self._lib = _lib.load()  # raises when the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("NeighListGPU needs a HIP device; there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.dtype = dtype
+        self._h = C.c_void_p()
+        check(
+            self._lib.nl_create(C.byref(self._h), _lib.NL_F32 if dtype == torch.float32 else _lib.NL_F64,
+                                float(search_length), float(Lx), float(Ly), float(Lz), self.device.index or 0),
+            "nl_create",
+        )
+        mesh = (C.c_int32 * 3)()
+        ncell = C.c_int64()
+        check(self._lib.nl_get_mesh(self._h, C.byref(mesh), C.byref(ncell)))
+        self.mesh_size = tuple(mesh)
+        self.number_of_mesh = int(ncell.value)
+        self._n = 0
+        self._n_rows = 0
+        self._q = None  # keeps the positions of an asynchronous build alive
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.nl_destroy(h)
+            except Exception:  # pragma: no cover
+                pass
+
+    # ------------------------------------------------------------------ reference surface
+    def Initialize(self, particle_number):
+        """neighlist_gpu.hpp:268-287 / neighlist_cpu.hpp:408-415."""
+        check(self._lib.nl_initialize(self._h, int(particle_number)), "nl_initialize")
+
+    def set_capacity(self, max_pairs):
+        check(self._lib.nl_set_capacity(self._h, int(max_pairs)), "nl_set_capacity")
+
+    def _check_q(self, q, n):
+        if not isinstance(q, torch.Tensor) or q.device.type != "cuda":
+            raise TypeError("q must be a torch tensor on the HIP device")
+        if q.dtype != self.dtype or q.dim() != 2 or q.shape[1] not in (3, 4) or not q.is_contiguous():
+            raise TypeError(f"q must be a contiguous (N, 3|4) tensor of {self.dtype}")
+        n = q.shape[0] if n is None else int(n)
+        if n > q.shape[0]:
+            raise ValueError("particle_number exceeds the buffer")
+        return n
+
+    def MakeNeighList(self, q, particle_number=None, sync=True, tblock_size=128, smem_hei=7):
+        """neighlist_gpu.hpp:289-466.  ``tblock_size``/``smem_hei`` select among the reference's CUDA variants
+        and are accepted for source compatibility only."""
+        n = self._check_q(q, particle_number)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._q = q
+        self._n = self._n_rows = n
+        check(self._lib.nl_make_list(self._h, q.data_ptr(), q.shape[1], n, stream, 1 if sync else 0), "nl_make_list")
+
+    def MakeNeighListSlab(self, q, gid, n_rows, z_lo, z_hi, sync=True):
+        """Domain-decomposed build: rows for the first ``n_rows`` (owned) particles, the rest
+        are ghosts of the two neighbouring cell layers; ``gid`` are global ids (int32 device tensor or None)."""
+        n = self._check_q(q, None)
+        if gid is not None:
+            if gid.device.type != "cuda" or gid.dtype != torch.int32 or gid.numel() != n or not gid.is_contiguous():
+                raise TypeError("gid must be a contiguous int32 device tensor with one id per particle")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._q = (q, gid)
+        self._n, self._n_rows = n, int(n_rows)
+        check(
+            self._lib.nl_make_list_slab(self._h, q.data_ptr(), q.shape[1], gid.data_ptr() if gid is not None else None,
+                                        int(n_rows), n, int(z_lo), int(z_hi), stream, 1 if sync else 0),
+            "nl_make_list_slab",
+        )
+
+    def synchronize(self):
+        check(self._lib.nl_synchronize(self._h), "nl_synchronize")
+
+    def neigh_list(self):
+        """neighlist_gpu.hpp:468-474: full list, transposed, ``[k, i]`` = k-th neighbour of i, -1 padded."""
+        lst, cnt, stride, mx = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int32()
+        check(self._lib.nl_get_full_transposed(self._h, C.byref(lst), C.byref(cnt), C.byref(stride), C.byref(mx)),
+              "nl_get_full_transposed")
+        return _as_tensor(lst.value, (max(mx.value, 1), stride.value), "<i4", self, self.device)
+
+    def number_of_partners(self):
+        """neighlist_gpu.hpp:476-482: full counts."""
+        lst, cnt, stride, mx = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int32()
+        check(self._lib.nl_get_full_transposed(self._h, C.byref(lst), C.byref(cnt), C.byref(stride), C.byref(mx)),
+              "nl_get_full_transposed")
+        return _as_tensor(cnt.value, (stride.value,), "<i4", self, self.device)
+
+    def number_of_pairs(self):
+        """neighlist_gpu.hpp:484-487: the sum of the FULL counts (= 2 x half pairs)."""
+        return 2 * self.half_number_of_pairs()
+
+    # ------------------------------------------------------------------ CPU-class surface (half CSR)
+    def _half(self):
+        kp, sl, nop, npairs = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self._lib.nl_get_half_csr(self._h, C.byref(kp), C.byref(sl), C.byref(nop), C.byref(npairs)),
+              "nl_get_half_csr")
+        return kp.value, sl.value, nop.value, int(npairs.value)
+
+    def half_number_of_pairs(self):
+        """neighlist_cpu.hpp:437-439."""
+        npairs = C.c_int64()
+        check(self._lib.nl_number_of_pairs(self._h, C.byref(npairs)), "nl_number_of_pairs")
+        return int(npairs.value)
+
+    def key_pointer(self):
+        """neighlist_cpu.hpp:449-455 (view, valid until the next build)."""
+        kp, _, _, _ = self._half()
+        return _as_tensor(kp, (self._n_rows + 1,), "<i4", self, self.device)
+
+    def sorted_list(self):
+        """neighlist_cpu.hpp:441-447 (view, valid until the next build)."""
+        _, sl, _, npairs = self._half()
+        return _as_tensor(sl, (npairs,), "<i4", self, self.device)
+
+    def half_number_of_partners(self):
+        """neighlist_cpu.hpp:457-463 (view, valid until the next build)."""
+        _, _, nop, _ = self._half()
+        return _as_tensor(nop, (self._n_rows,), "<i4", self, self.device)
+
+    # ------------------------------------------------------------------ introspection
+    def sorted_state(self):
+        """(cell_start, sorted_row) of the last build -- for tests of the hash/sort stage."""
+        cs, sp, sr, ncl = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self._lib.nl_get_sorted(self._h, C.byref(cs), C.byref(sp), C.byref(sr), C.byref(ncl)), "nl_get_sorted")
+        return (_as_tensor(cs.value, (ncl.value + 1,), "<i4", self, self.device),
+                _as_tensor(sr.value, (self._n,), "<i4", self, self.device))
+
+    def profile_stages(self, q, reps=10):
+        """Average device milliseconds per pipeline stage (HIP events on the launch stream)."""
+        n = self._check_q(q, None)
+        ms = (C.c_double * _lib.NL_NUM_STAGES)()
+        check(self._lib.nl_profile_stages(self._h, q.data_ptr(), q.shape[1], n, int(reps), C.byref(ms)),
+              "nl_profile_stages")
+        self._n = self._n_rows = n
+        return dict(zip(_lib.STAGE_NAMES, (float(v) for v in ms)))
+
+
+    def profile_last_build(self, reps=10):
+        """Same for the last build (also a slab build); its position/id tensors are kept alive by this object."""
+        ms = (C.c_double * _lib.NL_NUM_STAGES)()
+        check(self._lib.nl_profile_last_build(self._h, int(reps), C.byref(ms)), "nl_profile_last_build")
+        return dict(zip(_lib.STAGE_NAMES, (float(v) for v in ms)))
+
+
+def device_count() -> int:
+    c = C.c_int()
+    check(_lib.load().nl_device_count(C.byref(c)))
+    return int(c.value)

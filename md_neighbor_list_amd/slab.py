@@ -1,0 +1,174 @@
+"""Multi-GPU domain decomposition: z-slabs of the cell mesh + one-cell ghost-layer exchange.
+
+The reference is single-GPU; this is new functionality.  The box is cut along z into ``world`` slabs of whole cell
+layers of the GLOBAL mesh (mesh_z = int(Lz / rc), exactly the reference's mesh, neighlist_cpu.hpp:384-386).  Rank r
+owns the particles whose reference cell lies in its layers [z_lo, z_hi) and receives, every build, the particles of
+the two periodic neighbour layers z_lo-1 and z_hi (mod mesh_z) from ranks r-1 and r+1: positions unshifted (the
+reference wraps cell indices but never applies a minimum image, neighlist_cpu.hpp:219-223) plus global ids.  It
+then builds rows for its owned particles only; a pair (i, j) lands in the row of min(i, j) on the rank that owns
+that particle, so the union over ranks is exactly the global half list.
+
+Communication is point-to-point only (``torch.distributed`` send/recv: RCCL over xGMI with the ``nccl`` backend,
+``gloo`` on CPU for tests); there is no collective on the data path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def mesh_of(box, rc):
+    """mesh_size[d] = (int)(L_d / rc), neighlist_cpu.hpp:384-386."""
+    return tuple(int(b / rc) for b in box)
+
+
+def split_layers(mesh_z: int, world: int):
+    """[z_lo, z_hi) per rank: contiguous, as even as possible.  Every rank needs >= 1 layer and the two ghost layers
+    of a rank must be distinct layers, i.e. mesh_z - owned >= 2."""
+    if world < 1 or mesh_z < 3:
+        raise ValueError("need world >= 1 and at least 3 cell layers")
+    base, rem = divmod(mesh_z, world)
+    if world > 1 and (base < 1 or mesh_z - (base + (1 if rem else 0)) < 2):
+        raise ValueError(f"cannot cut {mesh_z} cell layers into {world} slabs with distinct ghost layers")
+    out, z = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((z, z + n))
+        z += n
+    return out
+
+
+def z_layer(q: torch.Tensor, box, rc) -> torch.Tensor:
+    """The reference's z cell index of every particle: (int32)(z * ims_z), one periodic wrap
+    (GenHash + ApplyPBC, neighlist_cpu.hpp:51-66), with ims_z rounded to the position type as the class stores it
+    (neighlist_cpu.hpp:12,409-411).  The library re-derives this on the device and flags any disagreement
+    (NL_ERR_DOMAIN), so this copy of the rule cannot silently drift."""
+    mz = int(box[2] / rc)
+    if q.dtype == torch.float32:
+        ims = np.float32(1.0 / np.float64(np.float32(box[2] / mz)))
+        t = q[:, 2] * torch.tensor(ims, dtype=torch.float32, device=q.device)
+    else:
+        ims = 1.0 / (box[2] / mz)
+        t = q[:, 2] * torch.tensor(ims, dtype=torch.float64, device=q.device)
+    iz = t.to(torch.int32)  # truncation toward zero
+    iz = torch.where(iz < 0, iz + mz, iz)
+    iz = torch.where(iz >= mz, iz - mz, iz)
+    return iz
+
+
+@dataclass
+class SlabState:
+    rank: int
+    world: int
+    z_lo: int
+    z_hi: int
+    n_rows: int                # owned particles
+    q_all: torch.Tensor        # [n_rows + ghosts_max, 3|4] owned first, then ghost_low, ghost_high
+    gid_all: torch.Tensor      # int32 global ids, same order
+    send_lo_idx: torch.Tensor  # owned rows lying in layer z_lo      (go to rank-1 as its upper ghosts)
+    send_hi_idx: torch.Tensor  # owned rows lying in layer z_hi - 1  (go to rank+1 as its lower ghosts)
+    n_ghost_lo: int
+    n_ghost_hi: int
+
+    @property
+    def n_total(self):
+        return self.n_rows + self.n_ghost_lo + self.n_ghost_hi
+
+
+def _p2p(ops_spec, staging_cpu: bool):
+    """ops_spec: list of ("send"|"recv", tensor, peer).  One grouped batch of point-to-point transfers."""
+    if not ops_spec:
+        return
+    bufs, ops = [], []
+    for kind, t, peer in ops_spec:
+        if staging_cpu:
+            c = t.detach().to("cpu").contiguous() if kind == "send" else torch.empty(t.shape, dtype=t.dtype)
+            bufs.append((kind, t, c))
+            ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, c, peer))
+        else:
+            ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    for kind, t, c in bufs:
+        if kind == "recv":
+            t.copy_(c)
+
+
+def _staging():
+    return dist.get_backend() != "nccl"
+
+
+def setup(q_global: torch.Tensor, gid_global: torch.Tensor | None, box, rc, rank=None, world=None) -> SlabState:
+    """Initial scatter, outside the timed build (the reference copies positions to the device once before its
+    timing loop, make_list.cu:119,124): every rank looks at the whole (synthetic) box and keeps its slab.
+    Also exchanges the ghost counts once so that the per-build exchange needs no size negotiation."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    mz = int(box[2] / rc)
+    z_lo, z_hi = split_layers(mz, world)[rank]
+    iz = z_layer(q_global, box, rc)
+    if gid_global is None:
+        gid_global = torch.arange(q_global.shape[0], dtype=torch.int32, device=q_global.device)
+    own = (iz >= z_lo) & (iz < z_hi)
+    q_own = q_global[own].contiguous()
+    gid_own = gid_global[own].contiguous()
+    iz_own = iz[own]
+    send_lo = torch.nonzero(iz_own == z_lo).flatten()
+    send_hi = torch.nonzero(iz_own == z_hi - 1).flatten()
+    n_rows = int(q_own.shape[0])
+    n_glo = n_ghi = 0
+    if world > 1:
+        lo_peer, hi_peer = (rank - 1) % world, (rank + 1) % world
+        cnt_send = torch.tensor([send_lo.numel(), send_hi.numel()], dtype=torch.int64, device=q_global.device)
+        cnt_from_lo = torch.zeros(1, dtype=torch.int64, device=q_global.device)
+        cnt_from_hi = torch.zeros(1, dtype=torch.int64, device=q_global.device)
+        # a peer's bottom-layer count is MY upper-ghost count; with world == 2 both messages come from the same
+        # rank in the order [its bottom, its top], so receive the upper-ghost count first (see exchange_ghosts)
+        recvs = [("recv", cnt_from_hi, hi_peer), ("recv", cnt_from_lo, lo_peer)]
+        if lo_peer != hi_peer:
+            recvs.reverse()
+        _p2p([("send", cnt_send[0:1], lo_peer), ("send", cnt_send[1:2], hi_peer)] + recvs, _staging())
+        n_glo, n_ghi = int(cnt_from_lo.item()), int(cnt_from_hi.item())
+    q_all = torch.empty((n_rows + n_glo + n_ghi, q_global.shape[1]), dtype=q_global.dtype, device=q_global.device)
+    gid_all = torch.empty(n_rows + n_glo + n_ghi, dtype=torch.int32, device=q_global.device)
+    q_all[:n_rows] = q_own
+    gid_all[:n_rows] = gid_own
+    return SlabState(rank, world, z_lo, z_hi, n_rows, q_all, gid_all, send_lo, send_hi, n_glo, n_ghi)
+
+
+def exchange_ghosts(st: SlabState) -> None:
+    """The per-build halo exchange: my bottom layer goes down, my top layer goes up; the neighbours' layers land
+    directly in the ghost region of q_all / gid_all.  With world == 2 both neighbours are the same rank: the send
+    of my bottom layer pairs with its receive of 'upper ghosts' by message order inside the batch."""
+    if st.world == 1:
+        return
+    lo_peer, hi_peer = (st.rank - 1) % st.world, (st.rank + 1) % st.world
+    n0, n1 = st.n_rows, st.n_rows + st.n_ghost_lo
+    q_lo = st.q_all[:n0].index_select(0, st.send_lo_idx)
+    q_hi = st.q_all[:n0].index_select(0, st.send_hi_idx)
+    g_lo = st.gid_all[:n0].index_select(0, st.send_lo_idx)
+    g_hi = st.gid_all[:n0].index_select(0, st.send_hi_idx)
+    # Order matters when lo_peer == hi_peer (world 2): the peer posts [send lo, send hi, recv lo-ghosts, recv
+    # hi-ghosts]; its "send hi" (its top layer) is my lower ghost layer and its "send lo" my upper ghost layer.
+    # So receive from hi_peer-as-sender-of-lo FIRST when the peers coincide.
+    if lo_peer == hi_peer:
+        spec = [("send", q_lo, lo_peer), ("send", g_lo, lo_peer), ("send", q_hi, hi_peer), ("send", g_hi, hi_peer),
+                ("recv", st.q_all[n1:n1 + st.n_ghost_hi], hi_peer), ("recv", st.gid_all[n1:n1 + st.n_ghost_hi], hi_peer),
+                ("recv", st.q_all[n0:n1], lo_peer), ("recv", st.gid_all[n0:n1], lo_peer)]
+    else:
+        spec = [("send", q_lo, lo_peer), ("send", g_lo, lo_peer), ("send", q_hi, hi_peer), ("send", g_hi, hi_peer),
+                ("recv", st.q_all[n0:n1], lo_peer), ("recv", st.gid_all[n0:n1], lo_peer),
+                ("recv", st.q_all[n1:n1 + st.n_ghost_hi], hi_peer), ("recv", st.gid_all[n1:n1 + st.n_ghost_hi], hi_peer)]
+    _p2p(spec, _staging())
+
+
+def build(nl, st: SlabState, sync=True) -> None:
+    """One domain-decomposed build on this rank: halo exchange, then the slab build on owned + ghost particles."""
+    exchange_ghosts(st)
+    if st.world == 1:
+        nl.MakeNeighListSlab(st.q_all, st.gid_all, st.n_rows, 0, nl.mesh_size[2], sync=sync)
+    else:
+        nl.MakeNeighListSlab(st.q_all, st.gid_all, st.n_rows, st.z_lo, st.z_hi, sync=sync)

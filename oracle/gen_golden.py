@@ -94,5 +94,35 @@ def main():
         print(f"N={len(q):5d} mesh={mesh} P={h.npairs:7d} hash={h.hash():016x} dup={dup}")
 
 
+def big():
+    """Known answers at the BASELINE sizes (too big to store as lists): pair count, pair-set hash, a checksum of
+    number_of_partners, its maximum.  From the compiled reference (-DLOOP_FUSION build with pinned flags)."""
+    import json
+
+    out = {}
+    for name, gen, rc in (
+        ("u1M_rho1_f32", lambda: inputs.uniform_box(1 << 20, 1.0, np.float32), 3.3),   # BASELINE config 2
+        ("u1M_rho1_f64", lambda: inputs.uniform_box(1 << 20, 1.0, np.float64), 3.3),
+        ("u1M_rho05_f32", lambda: inputs.uniform_box(1 << 20, 0.5, np.float32), 3.3),  # BASELINE config 3
+        ("u1M_rho05_f64", lambda: inputs.uniform_box(1 << 20, 0.5, np.float64), 3.3),
+        ("fcc_L50_rho1_f64", lambda: inputs.fcc_box(1.0, 50.0, np.float64), 3.3),       # the README point
+        ("fcc_L50_rho05_f64", lambda: inputs.fcc_box(0.5, 50.0, np.float64), 3.3),
+        ("fcc_L50_rho1_f32", lambda: inputs.fcc_box(1.0, 50.0, np.float32), 3.3),
+    ):
+        q, box = gen()
+        h = po.ref_build(q, rc, box, "fused")[0]
+        nop = h.number_of_partners.astype(np.int64)
+        out[name] = {
+            "n": int(len(q)), "rc": rc, "box": list(box), "npairs": h.npairs, "hash": f"{h.hash():016x}",
+            "nop_max": int(nop.max()), "nop_weighted_sum": int((nop * (np.arange(len(nop)) % 1000003)).sum()),
+        }
+        print(name, out[name], flush=True)
+    with open(os.path.join(OUT, "known_answers.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    main()
+    if "--big" in sys.argv:
+        big()
+    else:
+        main()

@@ -1,0 +1,112 @@
+"""Worker of the multi-process slab tests (gloo, world_size >= 2).  mode "oracle": the per-rank build is emulated
+with the CPU oracle (CPU-only machines; checks decomposition, ghost exchange and the ownership rule).  mode "hip":
+every rank runs the real nl_make_list_slab on the (shared) GPU."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pairs_of(kp, lst, row_gid=None):
+    rows = np.repeat(np.arange(len(kp) - 1, dtype=np.int64), np.diff(kp))
+    if row_gid is not None:
+        rows = row_gid.astype(np.int64)[rows]
+    return (rows << 32) | lst.astype(np.int64)
+
+
+def worker(rank, world, port, mode, case, ret):
+    import torch
+    import torch.distributed as dist
+
+    from md_neighbor_list_amd import inputs, slab
+    from oracle import pyoracle as po
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, box, rc, dtype, seed = case
+        q, box = inputs.uniform_box(n, dtype=np.dtype(dtype).type, seed=seed, box=box)
+        dev = "cuda" if mode == "hip" else "cpu"
+        qt = torch.from_numpy(q).to(dev)
+        st = slab.setup(qt, None, box, rc)
+        if mode == "oracle":
+            slab.exchange_ghosts(st)
+            lq, gid = st.q_all.numpy(), st.gid_all.numpy()
+            # every ghost must lie in one of my two neighbour layers, every owned particle in my slab
+            iz = slab.z_layer(st.q_all, box, rc).numpy()
+            mz = int(box[2] / rc)
+            assert np.all((iz[: st.n_rows] >= st.z_lo) & (iz[: st.n_rows] < st.z_hi))
+            n1 = st.n_rows + st.n_ghost_lo
+            assert np.all(iz[st.n_rows:n1] == (st.z_lo - 1) % mz) and np.all(iz[n1:] == st.z_hi % mz)
+            h = po.build(lq, rc, box)
+            a = np.repeat(np.arange(len(lq), dtype=np.int64), np.diff(h.key_pointer))
+            b = h.sorted_list.astype(np.int64)
+            ga, gb = gid[a].astype(np.int64), gid[b].astype(np.int64)
+            lo_is_a = ga < gb
+            keep = np.where(lo_is_a, a, b) < st.n_rows  # the particle with the smaller global id is mine
+            mine = (np.minimum(ga, gb)[keep] << 32) | np.maximum(ga, gb)[keep]
+        else:
+            from md_neighbor_list_amd import NeighListGPU
+
+            tdt = torch.float32 if q.dtype == np.float32 else torch.float64
+            nl = NeighListGPU(rc, *box, dtype=tdt)
+            nl.Initialize(st.q_all.shape[0])
+            slab.build(nl, st, sync=True)
+            kp = nl.key_pointer().cpu().numpy()
+            sl = nl.sorted_list().cpu().numpy()
+            assert len(kp) == st.n_rows + 1
+            mine = pairs_of(kp, sl, st.gid_all[: st.n_rows].cpu().numpy())
+            # second build, asynchronous, must agree
+            slab.build(nl, st, sync=False)
+            nl.synchronize()
+            again = pairs_of(nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy(),
+                             st.gid_all[: st.n_rows].cpu().numpy())
+            assert np.array_equal(np.sort(mine), np.sort(again))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine, st.n_rows, st.n_ghost_lo, st.n_ghost_hi))
+        if rank == 0:
+            ref = po.build(q, rc, box)
+            want = np.sort(pairs_of(ref.key_pointer, ref.sorted_list))
+            got = np.sort(np.concatenate([g[0] for g in gathered]))
+            assert sum(g[1] for g in gathered) == n
+            assert len(got) == len(want) == ref.npairs, (len(got), len(want))
+            assert np.array_equal(got, want)
+            assert len(np.unique(got)) == len(got)  # every pair exactly once over all ranks
+            ret.put(("ok", ref.npairs, [g[1:] for g in gathered]))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        ret.put(("fail", rank, traceback.format_exc()))
+        raise e
+    finally:
+        dist.destroy_process_group()
+
+
+def run(world, mode, case, timeout=600):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, mode, case, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = ret.get(timeout=timeout)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert res[0] == "ok", res
+    return res

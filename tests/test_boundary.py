@@ -1,0 +1,77 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports everything include/nl_hip.h declares, and
+the product package never touches the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "md_neighbor_list_amd", "lib", "libnl_hip.so")
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    for must in ("nl_create", "nl_initialize", "nl_make_list", "nl_make_list_slab", "nl_get_half_csr",
+                 "nl_get_full_transposed", "nl_number_of_pairs", "nl_destroy", "nl_buf_alloc"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(LIB):
+        pytest.fail(f"{LIB} missing: __graft_entry__.build() / `make lib` must run before the tests")
+    lib = ctypes.CDLL(LIB)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+    from md_neighbor_list_amd import _lib
+
+    assert sorted(_lib.PROTOTYPES) == declared_symbols()  # the Python binding covers the whole header
+    _lib.load()
+    assert _lib.load().nl_status_string(7).decode().startswith("fewer than 3")
+
+
+def test_argument_errors_without_a_device():
+    """Calls that fail before touching the GPU behave the same on a CPU-only machine."""
+    from md_neighbor_list_amd import _lib
+
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.nl_create(ctypes.byref(h), 0, -1.0, 10.0, 10.0, 10.0, 0) == _lib.NL_ERR_ARG
+    assert lib.nl_create(ctypes.byref(h), 5, 3.3, 10.0, 10.0, 10.0, 0) == _lib.NL_ERR_ARG
+    assert lib.nl_create(ctypes.byref(h), 0, 3.3, 9.0, 10.0, 10.0, 0) == _lib.NL_ERR_MESH  # int(9/3.3) = 2 cells
+    assert lib.nl_create(None, 0, 3.3, 10.0, 10.0, 10.0, 0) == _lib.NL_ERR_ARG
+    assert lib.nl_destroy(None) == _lib.NL_ERR_ARG
+    assert lib.nl_make_list(None, None, 4, 0, None, 1) == _lib.NL_ERR_ARG
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under md_neighbor_list_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "md_neighbor_list_amd")
+    bad = []
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".inc", ".h")):
+                t = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"\boracle\b|liboracle|nl_oracle|libnl_ref", t):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
+    out = subprocess.run(["ldd", LIB], capture_output=True, text=True).stdout if os.path.exists(LIB) else ""
+    assert "oracle" not in out and "nl_ref" not in out
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from md_neighbor_list_amd import NeighListGPU
+
+    with pytest.raises(RuntimeError):
+        NeighListGPU(3.3, 16.0, 16.0, 16.0)

@@ -1,0 +1,209 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+  * the golden fixtures generated from the compiled reference,
+  * the CPU oracle on seeded inputs (sizes the oracle finishes in seconds),
+  * size-independent properties and stored known answers at the BASELINE sizes.
+Integer results are compared bit-exactly after the reference's canonical sort (make_list.cpp:120-128,211-220).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from md_neighbor_list_amd import inputs
+from tests.util import GOLDEN, canonical_csr, golden_names, gpu_build, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _po():
+    from oracle import pyoracle as po
+
+    return po
+
+
+def _loaded_native():
+    """The HIP library must be what ran (no silent fallback exists, but say so explicitly)."""
+    with open("/proc/self/maps") as f:
+        return any("libnl_hip.so" in line for line in f)
+
+
+@pytest.mark.parametrize("name", golden_names(dup=False))
+def test_golden(name):
+    g = load_golden(name)
+    _, nop, kp, sl = gpu_build(g["q"], float(g["rc"]), tuple(g["box"]))
+    assert _loaded_native()
+    assert int(kp[-1]) == int(g["npairs"])
+    assert np.array_equal(nop, g["number_of_partners"])
+    assert np.array_equal(kp.astype(np.int64), g["key_pointer"])
+    assert np.array_equal(canonical_csr(kp, sl), g["sorted_list"])
+
+
+@pytest.mark.parametrize("name", ["u4096_rho1_f32", "sc_ties_f64", "outside_wrap_f32"])
+def test_golden_async_and_stride3(name):
+    """sync=False (the reference's timing loop, make_list.cu:124-127) and the 3-scalar Vec of make_list.cpp:26-32."""
+    g = load_golden(name)
+    q3 = np.ascontiguousarray(g["q"][:, :3])
+    _, nop, kp, sl = gpu_build(q3, float(g["rc"]), tuple(g["box"]), sync=False)
+    assert np.array_equal(nop, g["number_of_partners"])
+    assert np.array_equal(canonical_csr(kp, sl), g["sorted_list"])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("case", [
+    (20000, (30.0, 30.0, 30.0), 3.3, 21),    # rho 0.74
+    (50000, (36.84, 36.84, 36.84), 3.3, 22),  # rho 1.0, mesh 11
+    (30000, (25.0, 40.0, 33.0), 2.7, 23),    # non-cubic
+    (12000, (13.2, 13.2, 40.0), 3.3, 24),    # L = 4*rc exactly in x,y (hash rounding at cell faces)
+    (3000, (60.0, 60.0, 60.0), 3.3, 25),     # very sparse: mostly empty cells
+    (40000, (20.0, 20.0, 20.0), 3.3, 26),    # rho 5: long rows, stencil larger than one LDS batch (f64)
+])
+def test_against_oracle(case, dtype):
+    n, box, rc, seed = case
+    q, box = inputs.uniform_box(n, dtype=dtype, seed=seed, box=box)
+    ref = _po().build(q, rc, box)
+    _, nop, kp, sl = gpu_build(q, rc, box)
+    assert int(kp[-1]) == ref.npairs
+    assert np.array_equal(nop, ref.number_of_partners)
+    assert np.array_equal(kp.astype(np.int64), ref.key_pointer)
+    assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+
+
+def test_two_times_cutoff_fp64():
+    """BASELINE config 5 regime (fp64, rc = 6.6: ~560 half pairs per particle) at an oracle-sized N."""
+    q, box = inputs.uniform_box(32768, 1.0, np.float64, seed=31)
+    ref = _po().build(q, 6.6, box)
+    _, nop, kp, sl = gpu_build(q, 6.6, box)
+    assert int(kp[-1]) == ref.npairs
+    assert np.array_equal(nop, ref.number_of_partners)
+    assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+
+
+def test_hash_and_sort_stage():
+    """a3-a5: every particle lands in the cell the reference's GenHash gives it (neighlist_cpu.hpp:51-59)."""
+    import torch
+
+    q, box = inputs.uniform_box(100000, 1.0, np.float32, seed=41)
+    q[:50, :3] = np.nextafter(np.float32(box[0]), np.float32(0))  # rounds up to the box edge -> wraps to cell 0
+    cells, mesh = _po().cells(q, 3.3, box)
+    nl, nop, kp, sl = gpu_build(q, 3.3, box)
+    assert tuple(nl.mesh_size) == tuple(mesh)
+    cell_start, sorted_row = (t.cpu().numpy() for t in nl.sorted_state())
+    assert cell_start[0] == 0 and cell_start[-1] == len(q) and np.all(np.diff(cell_start) >= 0)
+    assert np.array_equal(np.sort(sorted_row), np.arange(len(q)))
+    cell_of_slot = np.repeat(np.arange(len(cell_start) - 1), np.diff(cell_start))
+    assert np.array_equal(cells[sorted_row], cell_of_slot)
+    assert np.array_equal(np.bincount(cells, minlength=len(cell_start) - 1), np.diff(cell_start))
+    del torch
+
+
+def test_full_transposed_list_matches_gpu_harness_check():
+    """The GPU class's output (neighlist_gpu.hpp:468-487) checked the way make_list.cu:157-198 does."""
+    q, box = inputs.uniform_box(6000, dtype=np.float64, seed=51, box=(18.0, 18.0, 18.0))
+    nl, nop, kp, sl = gpu_build(q, 3.3, box)
+    ref = _po().bruteforce(q, 3.3)
+    tl = nl.neigh_list().cpu().numpy()
+    cnt = nl.number_of_partners().cpu().numpy()
+    n = len(q)
+    assert nl.number_of_pairs() == 2 * ref.npairs == int(cnt.sum())
+    full = [[] for _ in range(n)]
+    rows = np.repeat(np.arange(n), np.diff(ref.key_pointer))
+    for i, j in zip(rows, ref.sorted_list):
+        full[i].append(j)
+        full[j].append(i)
+    for i in range(n):
+        assert cnt[i] == len(full[i])
+        assert sorted(tl[: cnt[i], i].tolist()) == sorted(full[i])
+        assert np.all(tl[cnt[i]:, i] == -1)
+    h, nhalf = _po().hash_transposed(cnt, tl, n)
+    assert nhalf == ref.npairs and h == ref.hash()
+
+
+def test_errors_are_reported_not_crashes():
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU, NLError
+    from md_neighbor_list_amd import _lib
+
+    with pytest.raises(NLError) as e:
+        NeighListGPU(3.3, 9.0, 20.0, 20.0)  # 2 cells along x
+    assert e.value.code == _lib.NL_ERR_MESH
+    q, box = inputs.uniform_box(5000, dtype=np.float32, seed=61, box=(17.0, 17.0, 17.0))
+    nl = NeighListGPU(3.3, *box)
+    qd = torch.from_numpy(q).cuda()
+    with pytest.raises(NLError) as e:
+        nl.MakeNeighList(qd)  # before Initialize
+    assert e.value.code == _lib.NL_ERR_STATE
+    nl.Initialize(len(q))
+    bad = q.copy()
+    bad[123, 2] = 60.0
+    with pytest.raises(NLError) as e:
+        nl.MakeNeighList(torch.from_numpy(bad).cuda())
+    assert e.value.code == _lib.NL_ERR_OUT_OF_BOX
+    bad[123, 2] = np.nan
+    with pytest.raises(NLError) as e:
+        nl.MakeNeighList(torch.from_numpy(bad).cuda())
+    assert e.value.code == _lib.NL_ERR_OUT_OF_BOX
+    # capacity: an asynchronous build cannot grow the list and must say so instead of overrunning
+    nl.set_capacity(1000)
+    nl.MakeNeighList(qd, sync=False)
+    with pytest.raises(NLError) as e:
+        nl.synchronize()
+    assert e.value.code == _lib.NL_ERR_CAPACITY
+    # a synchronous build grows it and succeeds, and the handle is reusable after every error above
+    nl.MakeNeighList(qd, sync=True)
+    ref = _po().build(q, 3.3, box)
+    assert nl.half_number_of_pairs() == ref.npairs
+    assert np.array_equal(canonical_csr(nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()),
+                          ref.canonical().sorted_list)
+
+
+def test_empty_and_tiny_inputs():
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    nl = NeighListGPU(3.3, 12.0, 12.0, 12.0)
+    nl.Initialize(16)
+    nl.MakeNeighList(torch.zeros((0, 4), dtype=torch.float32, device="cuda"))
+    assert nl.half_number_of_pairs() == 0 and nl.key_pointer().cpu().tolist() == [0]
+    q = torch.tensor([[1.0, 1.0, 1.0, 0.0], [2.0, 1.0, 1.0, 0.0], [11.9, 11.9, 11.9, 0.0]], device="cuda")
+    nl.MakeNeighList(q)
+    assert nl.half_number_of_pairs() == 1
+    assert nl.key_pointer().cpu().tolist() == [0, 1, 1, 1] and nl.sorted_list().cpu().tolist() == [1]
+
+
+@pytest.mark.parametrize("key", ["u1M_rho1_f32", "u1M_rho05_f32", "u1M_rho1_f64", "fcc_L50_rho1_f64"])
+def test_baseline_sizes_known_answers(key):
+    """BASELINE configs 2 and 3 (and the README lattice) at full size: pair count, pair-set hash and count checksum
+    against answers stored from the compiled reference; plus structural properties that need no oracle."""
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))[key]
+    dt = np.float32 if key.endswith("f32") else np.float64
+    if key.startswith("fcc"):
+        q, box = inputs.fcc_box(1.0, 50.0, dt)
+    else:
+        q, box = inputs.uniform_box(ka["n"], 1.0 if "rho1" in key else 0.5, dt)
+    assert len(q) == ka["n"]
+    nl, nop, kp, sl = gpu_build(q, ka["rc"], box)
+    assert int(kp[-1]) == ka["npairs"] == len(sl)
+    assert int(nop.max()) == ka["nop_max"]
+    assert int((nop.astype(np.int64) * (np.arange(len(nop)) % 1000003)).sum()) == ka["nop_weighted_sum"]
+    assert np.array_equal(np.diff(kp), nop)
+    rows = np.repeat(np.arange(len(nop), dtype=np.int32), nop)
+    assert np.all(sl > rows)  # half list: stored on the smaller id
+    from oracle import pyoracle as po
+
+    h = po.HalfList(nop, kp.astype(np.int64), sl).hash()
+    assert f"{h:016x}" == ka["hash"]
+    # idempotence: a second build of the same positions gives the same canonical list
+    nl2, nop2, kp2, sl2 = gpu_build(q, ka["rc"], box, sync=False)
+    assert np.array_equal(kp, kp2)
+    assert po.HalfList(nop2, kp2.astype(np.int64), sl2).hash() == h
+    # spot-check rows against an O(N) scan of all particles for a few i
+    rng = np.random.default_rng(3)
+    rc2 = ka["rc"] * ka["rc"]
+    for i in rng.integers(0, len(q), size=8):
+        d = q[:, :3] - q[i, :3]
+        r2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        want = np.nonzero(~(r2.astype(np.float64) > rc2) & (np.arange(len(q)) > i))[0]
+        assert np.array_equal(np.sort(sl[kp[i]:kp[i + 1]]), want.astype(np.int32))

@@ -1,0 +1,101 @@
+"""CPU tests: the oracle (oracle/nl_oracle.c) is pinned against the reference's outputs.
+
+  * every golden fixture under tests/golden/ (generated from the compiled reference by oracle/gen_golden.py)
+  * the compiled reference itself where oracle/_ref exists (raw array equality, WITHOUT_LOOP_FUSION order)
+  * the harness's brute-force definition (make_list.cpp:79-99)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from md_neighbor_list_amd import inputs
+from oracle import pyoracle as po
+from tests.util import GOLDEN, canonical_csr, golden_names, load_golden
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_restatement_matches_golden(name):
+    g = load_golden(name)
+    h = po.build(g["q"], float(g["rc"]), tuple(g["box"]))
+    assert h.npairs == int(g["npairs"])
+    assert np.array_equal(h.number_of_partners, g["number_of_partners"])
+    assert np.array_equal(h.key_pointer, g["key_pointer"])
+    # visit order of the WITHOUT_LOOP_FUSION variant, entry by entry
+    assert np.array_equal(h.sorted_list, g["sorted_list_naive_order"])
+    c = h.canonical()
+    assert np.array_equal(c.sorted_list, g["sorted_list"])
+    assert c.hash() == int(g["hash"])
+    # numpy canonicalisation (used by the GPU tests) agrees with the C one
+    assert np.array_equal(canonical_csr(h.key_pointer, h.sorted_list), g["sorted_list"])
+
+
+@pytest.mark.parametrize("name", golden_names(dup=False))
+def test_golden_is_a_set_of_ordered_pairs(name):
+    g = load_golden(name)
+    kp, lst = g["key_pointer"], g["sorted_list"]
+    rows = np.repeat(np.arange(len(kp) - 1), np.diff(kp))
+    assert np.all(lst > rows)  # stored on min(i,j): neighlist_cpu.hpp:225-236
+    pairs = rows.astype(np.int64) << 32 | lst
+    assert len(np.unique(pairs)) == len(pairs)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names(dup=False) if not n.startswith(("sc_", "u4096", "u3000"))])
+def test_bruteforce_agrees_where_cells_are_wider_than_cutoff(name):
+    """make_list.cpp:166-220: the harness checks the class against O(N^2).  (The sc_* lattices sit on L = m*rc
+    exactly, where hash rounding decides cell membership; there the class, not brute force, is the contract.)"""
+    g = load_golden(name)
+    b = po.bruteforce(g["q"], float(g["rc"]))
+    assert b.npairs == int(g["npairs"])
+    assert np.array_equal(b.sorted_list, g["sorted_list"])
+
+
+@pytest.mark.parametrize("variant", ["naive", "fused"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_restatement_matches_compiled_reference(variant, dtype):
+    if not po.ref_available(variant):
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    for seed, n, box, rc in ((1, 700, (11.0, 12.0, 13.5), 3.3), (2, 2500, (20.0, 20.0, 20.0), 3.3), (3, 900, (9.0, 30.0, 9.5), 2.9)):
+        q, box = inputs.uniform_box(n, dtype=dtype, seed=seed, box=box)
+        r, _, _ = po.ref_build(q, rc, box, variant)
+        h = po.build(q, rc, box)
+        assert np.array_equal(r.key_pointer, h.key_pointer)
+        assert np.array_equal(r.number_of_partners, h.number_of_partners)
+        if variant == "naive":
+            assert np.array_equal(r.sorted_list, h.sorted_list)
+        assert np.array_equal(r.canonical().sorted_list, h.canonical().sorted_list)
+
+
+def test_known_answer_config1():
+    """N=4096 rho=1.0 -> P = 243 701, hash 994f529891f2f789 (f32 == f64)."""
+    for dt in (np.float32, np.float64):
+        q, box = inputs.uniform_box(4096, 1.0, dt)
+        h = po.build(q, 3.3, box)
+        assert h.npairs == 243701 and h.hash() == 0x994F529891F2F789
+
+
+def test_reference_harness_lattice_counts():
+    """make_list.cpp:17-24 problem: N = 119 164 / 62 500 particles."""
+    for rho, n in ((1.0, 119164), (0.5, 62500)):
+        q, _ = inputs.fcc_box(rho, 50.0, np.float64)
+        assert len(q) == n
+        assert float(q[:, :3].max()) < 50.0
+
+
+@pytest.mark.slow
+def test_known_answer_lattice_pairs():
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+    q, box = inputs.fcc_box(0.5, 50.0, np.float64)
+    h = po.build(q, 3.3, box)
+    assert h.npairs == ka["fcc_L50_rho05_f64"]["npairs"] == 2268138
+    assert f"{h.hash():016x}" == ka["fcc_L50_rho05_f64"]["hash"]
+
+
+def test_out_of_box_is_reported():
+    q, box = inputs.uniform_box(100, dtype=np.float32, seed=5, box=(12.0, 12.0, 12.0))
+    q[7, 1] = 40.0  # more than one box length outside: the reference would index out of bounds
+    with pytest.raises(po.OracleError):
+        po.build(q, 3.3, box)
+    c, mesh = po.cells(q, 3.3, box)
+    assert c[7] == -1 and np.all(c[np.arange(100) != 7] >= 0) and tuple(mesh) == (3, 3, 3)

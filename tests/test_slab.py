@@ -1,0 +1,53 @@
+"""Multi-process tests of the slab decomposition: world_size 2 and 3 over gloo.
+CPU: decomposition + ghost exchange + ownership rule, per-rank build emulated by the oracle.
+GPU: the same with the real nl_make_list_slab on every rank (ranks share the one GPU of the test box)."""
+import numpy as np
+import pytest
+
+from md_neighbor_list_amd import slab
+from tests.slab_worker import run
+
+
+def test_split_layers():
+    assert slab.split_layers(30, 8) == [(0, 4), (4, 8), (8, 12), (12, 16), (16, 20), (20, 24), (24, 27), (27, 30)]
+    assert slab.split_layers(97, 8)[0] == (0, 13) and slab.split_layers(97, 8)[-1] == (85, 97)
+    assert slab.split_layers(5, 1) == [(0, 5)]
+    with pytest.raises(ValueError):
+        slab.split_layers(3, 2)  # a rank with 2 of 3 layers would see the same layer as both ghosts
+    with pytest.raises(ValueError):
+        slab.split_layers(4, 8)
+
+
+def test_z_layer_matches_oracle_hash():
+    import torch
+
+    from md_neighbor_list_amd import inputs
+    from oracle import pyoracle as po
+
+    for dt in (np.float32, np.float64):
+        q, box = inputs.uniform_box(20000, dtype=dt, seed=9, box=(13.2, 13.2, 26.4))
+        q[:100, 2] = np.nextafter(dt(26.4), dt(0))
+        q[100:200, 2] = dt(-0.5)
+        cells, mesh = po.cells(q, 3.3, box)
+        iz = slab.z_layer(torch.from_numpy(q), box, 3.3).numpy()
+        assert np.array_equal(iz, cells // (mesh[0] * mesh[1]))
+
+
+@pytest.mark.parametrize("world,case", [
+    (2, (6000, (14.0, 14.0, 20.0), 3.3, "float32", 71)),   # 6 layers: 3 + 3
+    (3, (9000, (13.5, 15.0, 30.0), 3.3, "float64", 72)),   # 9 layers: 3 + 3 + 3
+    (2, (4000, (12.0, 12.0, 17.0), 3.3, "float32", 73)),   # 5 layers: 3 + 2
+])
+def test_slab_union_equals_global_list_cpu(world, case):
+    res = run(world, "oracle", case)
+    assert res[0] == "ok"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case", [
+    (2, (60000, (30.0, 30.0, 66.0), 3.3, "float32", 81)),
+    (3, (50000, (25.0, 25.0, 80.0), 3.3, "float64", 82)),
+])
+def test_slab_union_equals_global_list_gpu(world, case):
+    res = run(world, "hip", case)
+    assert res[0] == "ok"

@@ -1,0 +1,49 @@
+#!/bin/bash
+# tools/gpu_session.sh -- one gpurun call: smoke, GPU tests, bench, rocprofv3 passes.
+# Every step runs under its own timeout; a step that times out or is killed ends the session (no further GPU
+# work is started after a hang).  Outputs go to gpurun_out/<tag>/.
+#   usage: tools/gpu_session.sh <tag> [steps...]     steps: smoke micro tests bench prof pmc
+set -u
+TAG=${1:-s}
+shift || true
+STEPS=${*:-"smoke micro tests bench prof pmc"}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+
+run() {  # run <seconds> <logfile> cmd...
+  local secs=$1 log=$2
+  shift 2
+  echo "== $* (limit ${secs}s) -> $log"
+  timeout -k 10 "$secs" "$@" > "$log" 2>&1
+  local rc=$?
+  echo "   exit $rc"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then
+    echo "TIMEOUT/KILL in: $* -- stopping the session here"
+    tail -5 "$log"
+    exit $rc
+  fi
+  return $rc
+}
+
+for s in $STEPS; do
+  case $s in
+    smoke) run 300 "$OUT/smoke.log" python -c "import __graft_entry__ as g; g.smoke()"; tail -3 "$OUT/smoke.log" ;;
+    micro) run 120 "$OUT/microbench.log" ./tools/microbench; cat "$OUT/microbench.log" ;;
+    tests) run 900 "$OUT/pytest_gpu.log" python -m pytest tests -m gpu -q -x --durations=8; tail -25 "$OUT/pytest_gpu.log" ;;
+    bench) run 420 "$OUT/bench.log" python bench.py --steps 50 --warmup 5; tail -3 "$OUT/bench.log" ;;
+    bench05) run 300 "$OUT/bench_cfg3.log" python bench.py --steps 50 --warmup 5 --workload cfg3 --no-cpu-baseline; tail -2 "$OUT/bench_cfg3.log" ;;
+    prof)
+      rm -rf "$OUT/prof"
+      run 420 "$OUT/rocprof_stats.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline
+      find "$OUT/prof" -name "*kernel_stats.csv" -exec cat {} \; | head -30 ;;
+    pmc)
+      rm -rf "$OUT/pmc_r" "$OUT/pmc_w" "$OUT/pmc_sq"
+      run 420 "$OUT/pmc_r.log" rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_r" -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --profile-reps 1 &&
+      run 420 "$OUT/pmc_w.log" rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --profile-reps 1 &&
+      run 420 "$OUT/pmc_sq.log" rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --profile-reps 1
+      python tools/summarize_pmc.py "$OUT" > "$OUT/pmc_summary.txt" 2>&1; cat "$OUT/pmc_summary.txt" ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
+echo "session $TAG done"
