@@ -132,6 +132,11 @@ template <typename T> Grid<T> make_grid(nl_handle_t h, int32_t n_rows, int32_t z
 
 // exclusive scan of in[n] into out[n+1]; grand total to total[0]
 int launch_scan(nl_handle_t h, const int32_t* in, int64_t n, int32_t* out, int64_t* total, hipStream_t s) {
+  if (n <= 0) {  // nothing to scan: out[0] = 0, total = 0 (a zero-size grid is not a valid launch)
+    HIPCHK(h, hipMemsetAsync(out, 0, sizeof(int32_t), s));
+    HIPCHK(h, hipMemsetAsync(total, 0, sizeof(int64_t), s));
+    return NL_OK;
+  }
   const int32_t nb = (int32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum);
   hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, h->block_sum, nb, total);
@@ -182,17 +187,16 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
   if (n > 0) hipLaunchKernelGGL((k_hash<T>), dim3(nbp), dim3(256), 0, s, q, stride, n, g, h->cell_count, h->rank, h->status);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_CELL_SCAN], s));
-  launch_scan(h, h->cell_count, ncl, h->cell_start, h->totals, s);
+  if (int rc = launch_scan(h, h->cell_count, ncl, h->cell_start, h->totals, s)) return rc;
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_REORDER], s));
   if (n > 0)
     hipLaunchKernelGGL((k_reorder<T>), dim3(nbp), dim3(256), 0, s, q, stride, gid, n, g, h->cell_start, h->rank,
                        static_cast<Pos<T>*>(h->sorted), h->sorted_row);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_COUNT], s));
-  // rows of particles that were rejected by the hash (error paths) must still hold a defined count
-  HIPCHK(h, hipMemsetAsync(h->count, 0, sizeof(int32_t) * (size_t)(n_rows > 0 ? n_rows : 1), s));
+  // (rows of particles rejected by the hash keep a stale count: such a build fails with its status anyway)
   launch_sweep<T>(h, MODE_COUNT, s);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_ROW_SCAN], s));
-  launch_scan(h, h->count, n_rows, h->key_pointer, h->totals + 1, s);
+  if (int rc = launch_scan(h, h->count, n_rows, h->key_pointer, h->totals + 1, s)) return rc;
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_FILL], s));
   launch_sweep<T>(h, MODE_FILL, s);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_TOTAL], s));

@@ -1,81 +1,155 @@
-// tools/microbench.hip -- VALU issue-rate probe for gfx950: how many cycles does a wave64 v_add_f32 /
-// v_pk_add_f32 / v_cmp cost at 1..8 waves per SIMD?  Decides whether packed fp32 halves the cost of the
-// distance test.  Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench tools/microbench.hip
+// tools/microbench.hip -- VALU issue-rate probe for gfx950 (MI355X).
+// For each instruction kind: real shader cycles per wave-instruction per SIMD at 1, 2, 4, 8 waves per SIMD, and
+// the clock the chip actually holds (s_memtime vs the 100 MHz s_memrealtime).  One 160-KiB-LDS block per CU pins
+// the placement (blocks of 256/512/1024 threads = 1/2/4 waves per SIMD; two 80-KiB blocks of 1024 for 8).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench tools/microbench.hip
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 
-#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+#define CHK(x)                                                                  \
+  do {                                                                          \
+    hipError_t e = (x);                                                         \
+    if (e != hipSuccess) {                                                      \
+      printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__);      \
+      return 1;                                                                 \
+    }                                                                           \
+  } while (0)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// 8 independent instructions, repeated 8 times = 64 per loop iteration
+#define REP8(X) X X X X X X X X
 
 template <int KIND>
-__global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
+__global__ void __launch_bounds__(1024) k(float* out, unsigned long long* stamps, int iters, float seed) {
+  extern __shared__ float lds[];
   float a0 = seed + threadIdx.x, a1 = a0 * 2, a2 = a0 * 3, a3 = a0 * 4, a4 = a0 * 5, a5 = a0 * 6, a6 = a0 * 7, a7 = a0 * 8;
+  f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
+  double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;
   const float b = seed * 0.5f;
+  const f2 bb = {b, b};
+  const double db = b;
+  const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b)));
+  unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  unsigned long long t0 = 0, r0 = 0, t1 = 0, r1 = 0;
+  __syncthreads();
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
   for (int i = 0; i < iters; i++) {
-    if (KIND == 0) {  // 8 independent v_add_f32
-      asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
-                   "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
-                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
-    } else if (KIND == 1) {  // 4 independent v_pk_add_f32 (8 float adds)
-      typedef float f2 __attribute__((ext_vector_type(2)));
-      f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, bb = {b, b};
-      asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
-                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(bb));
-      a0 = p0.x, a1 = p0.y, a2 = p1.x, a3 = p1.y, a4 = p2.x, a5 = p2.y, a6 = p3.x, a7 = p3.y;
-    } else if (KIND == 2) {  // 8 v_mul_f32
-      asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
-                   "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
-                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
-    } else if (KIND == 3) {  // 8 v_cmp_lt_f32 into SGPR pairs (the ballot path)
-      unsigned long long m0, m1, m2, m3;
-      asm volatile("v_cmp_lt_f32 %0, %4, %8\n v_cmp_lt_f32 %1, %5, %8\n v_cmp_lt_f32 %2, %6, %8\n v_cmp_lt_f32 %3, %7, %8\n"
-                   "v_cmp_lt_f32 %0, %5, %8\n v_cmp_lt_f32 %1, %6, %8\n v_cmp_lt_f32 %2, %7, %8\n v_cmp_lt_f32 %3, %4, %8\n"
-                   : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b));
-      a4 += (float)(m0 ^ m1 ^ m2 ^ m3);
-    } else if (KIND == 4) {  // 8 v_add_f64
-      double d0 = a0, d1 = a1, d2 = a2, d3 = a3, db = b;
-      asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
-                   "v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
-                   : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(db));
-      a0 = d0, a1 = d1, a2 = d2, a3 = d3;
-    } else if (KIND == 5) {  // 8 v_sub with an SGPR operand (the form the sweep uses)
-      asm volatile("v_subrev_f32 %0, %8, %0\n v_subrev_f32 %1, %8, %1\n v_subrev_f32 %2, %8, %2\n v_subrev_f32 %3, %8, %3\n"
-                   "v_subrev_f32 %4, %8, %4\n v_subrev_f32 %5, %8, %5\n v_subrev_f32 %6, %8, %6\n v_subrev_f32 %7, %8, %7\n"
-                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(b));
-    } else if (KIND == 6) {  // 8 v_mbcnt pairs -> 8 instructions (4 lo + 4 hi)
-      unsigned int u0 = __float_as_uint(a0), u1 = __float_as_uint(a1), u2 = __float_as_uint(a2), u3 = __float_as_uint(a3);
-      asm volatile("v_mbcnt_lo_u32_b32 %0, %0, 0\n v_mbcnt_hi_u32_b32 %0, %1, %0\n v_mbcnt_lo_u32_b32 %1, %1, 0\n v_mbcnt_hi_u32_b32 %1, %2, %1\n"
-                   "v_mbcnt_lo_u32_b32 %2, %2, 0\n v_mbcnt_hi_u32_b32 %2, %3, %2\n v_mbcnt_lo_u32_b32 %3, %3, 0\n v_mbcnt_hi_u32_b32 %3, %0, %3\n"
-                   : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
-      a0 = __uint_as_float(u0), a1 = __uint_as_float(u1), a2 = __uint_as_float(u2), a3 = __uint_as_float(u3);
+    if (KIND == 0) {
+      REP8(asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                        "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+    } else if (KIND == 1) {
+      REP8(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                        "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
+                        : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(bb));)
+    } else if (KIND == 2) {
+      REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                        "v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
+                        : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(bb));)
+    } else if (KIND == 3) {
+      REP8(asm volatile("v_pk_fma_f32 %0, %0, %8, %8\n v_pk_fma_f32 %1, %1, %8, %8\n v_pk_fma_f32 %2, %2, %8, %8\n v_pk_fma_f32 %3, %3, %8, %8\n"
+                        "v_pk_fma_f32 %4, %4, %8, %8\n v_pk_fma_f32 %5, %5, %8, %8\n v_pk_fma_f32 %6, %6, %8, %8\n v_pk_fma_f32 %7, %7, %8, %8\n"
+                        : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(bb));)
+    } else if (KIND == 4) {
+      REP8(asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                        "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+    } else if (KIND == 5) {  // compare into VCC (e32 encoding)
+      REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n"
+                        "v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 6) {  // compare into an arbitrary SGPR pair (e64 encoding)
+      REP8(asm volatile("v_cmp_lt_f32 %0, %4, %8\n v_cmp_lt_f32 %1, %5, %8\n v_cmp_lt_f32 %2, %6, %8\n v_cmp_lt_f32 %3, %7, %8\n"
+                        "v_cmp_lt_f32 %0, %5, %8\n v_cmp_lt_f32 %1, %6, %8\n v_cmp_lt_f32 %2, %7, %8\n v_cmp_lt_f32 %3, %4, %8\n"
+                        : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b));)
+    } else if (KIND == 7) {  // integer compare with an SGPR source into an SGPR pair
+      REP8(asm volatile("v_cmp_lt_i32 %0, %8, %4\n v_cmp_lt_i32 %1, %8, %5\n v_cmp_lt_i32 %2, %8, %6\n v_cmp_lt_i32 %3, %8, %7\n"
+                        "v_cmp_lt_i32 %0, %8, %5\n v_cmp_lt_i32 %1, %8, %6\n v_cmp_lt_i32 %2, %8, %7\n v_cmp_lt_i32 %3, %8, %4\n"
+                        : "=s"(m0), "=s"(m1), "=s"(m2), "=s"(m3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(sb));)
+    } else if (KIND == 8) {
+      REP8(asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+                        "v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n"
+                        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(db));)
+    } else if (KIND == 9) {
+      REP8(asm volatile("v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %8\n v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %8\n"
+                        "v_mul_f64 %4, %4, %8\n v_mul_f64 %5, %5, %8\n v_mul_f64 %6, %6, %8\n v_mul_f64 %7, %7, %8\n"
+                        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(db));)
+    } else if (KIND == 10) {
+      REP8(asm volatile("v_subrev_f32 %0, %8, %0\n v_subrev_f32 %1, %8, %1\n v_subrev_f32 %2, %8, %2\n v_subrev_f32 %3, %8, %3\n"
+                        "v_subrev_f32 %4, %8, %4\n v_subrev_f32 %5, %8, %5\n v_subrev_f32 %6, %8, %6\n v_subrev_f32 %7, %8, %7\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sb));)
+    } else if (KIND == 11) {  // the distance test as the sweep kernel issues it today: 8 instructions per test
+      REP8(asm volatile(
+               "v_subrev_f32 %0, %9, %4\n v_mul_f32 %0, %0, %0\n v_pk_add_f32 %1, %5, %6\n v_cmp_lt_i32 %2, %9, %4\n"
+               "v_pk_mul_f32 %1, %1, %1\n s_nop 0\n v_add_f32 %0, %0, %7\n v_add_f32 %0, %8, %0\n v_cmp_nlt_f32 %3, %9, %0\n"
+               : "=&v"(a4), "=&v"(p4), "=s"(m0), "=s"(m1)
+               : "v"(a0), "v"(p0), "v"(bb), "v"(a1), "v"(a2), "s"(sb));)
+    } else if (KIND == 12) {  // same test, all scalar-width ops (no packed): 10 instructions
+      REP8(asm volatile(
+               "v_subrev_f32 %0, %6, %3\n v_subrev_f32 %1, %6, %4\n v_subrev_f32 %2, %6, %5\n"
+               "v_mul_f32 %0, %0, %0\n v_mul_f32 %1, %1, %1\n v_mul_f32 %2, %2, %2\n"
+               "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %2\n v_cmp_lt_i32 %7, %6, %3\n v_cmp_nlt_f32 %8, %6, %0\n"
+               : "=&v"(a4), "=&v"(a5), "=&v"(a6)
+               : "v"(a0), "v"(a1), "v"(a2), "s"(sb), "s"(m0), "s"(m1));)
+    } else if (KIND == 13) {  // two tests per pass in packed form: 2 i-particles (SGPR pairs) against the same j
+      // 8 packed + 4 compares for 2 tests = 6 instructions per test; fixed registers (timing only)
+      REP8(asm volatile(
+               "v_pk_add_f32 v[100:101], v[110:111], s[40:41] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+               "v_pk_add_f32 v[102:103], v[112:113], s[42:43] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+               "v_pk_add_f32 v[104:105], v[114:115], s[44:45] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+               "v_pk_mul_f32 v[100:101], v[100:101], v[100:101]\n"
+               "v_pk_mul_f32 v[102:103], v[102:103], v[102:103]\n"
+               "v_pk_mul_f32 v[104:105], v[104:105], v[104:105]\n"
+               "v_pk_add_f32 v[100:101], v[100:101], v[102:103]\n"
+               "v_pk_add_f32 v[100:101], v[100:101], v[104:105]\n"
+               "v_cmp_lt_i32 s[52:53], s47, v116\n"
+               "v_cmp_lt_i32 s[54:55], s56, v116\n"
+               "v_cmp_nlt_f32 s[48:49], s46, v100\n"
+               "v_cmp_nlt_f32 s[50:51], s46, v101\n"
+               ::: "v100", "v101", "v102", "v103", "v104", "v105", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55");)
     }
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+  if ((threadIdx.x & 63) == 0) {
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    stamps[2 * w] = t1 - t0;
+    stamps[2 * w + 1] = r1 - r0;
+  }
+  float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.x + p2.x + p3.x + p4.y + p5.y + p6.y + p7.y;
+  s += (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) + (float)(m0 ^ m1 ^ m2 ^ m3);
+  if (s == 12345.678f) out[0] = s + lds[threadIdx.x];
 }
 
-template <int KIND> int run(const char* name, int ops_per_iter, float* out) {
+template <int KIND> int run(const char* name, int per_iter, float* out, unsigned long long* stamps_d) {
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
-  const int iters = 20000;
-  hipEvent_t e0, e1;
-  CHK(hipEventCreate(&e0));
-  CHK(hipEventCreate(&e1));
-  printf("%-28s", name);
-  for (int wps : {1, 2, 4, 8}) {  // waves per SIMD: blocks of 256 threads = 4 waves = 1 per SIMD
-    const int blocks = cus * wps;
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 100, 1.0f);
+  const int iters = 4000;
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  printf("%-34s", name);
+  for (int wps : {1, 2, 4, 8}) {
+    const int threads = wps >= 4 ? 1024 : 256 * wps;
+    const int blocks = wps == 8 ? 2 * cus : cus;
+    const size_t lds = wps == 8 ? 80 * 1024 : 160 * 1024;
+    const int nwaves = blocks * threads / 64;
+    std::vector<unsigned long long> st(2 * nwaves);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), lds, 0, out, stamps_d, 200, 1.0f);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), lds, 0, out, stamps_d, iters, 1.0f);
     CHK(hipDeviceSynchronize());
-    CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
-    CHK(hipEventRecord(e1));
-    CHK(hipDeviceSynchronize());
-    float ms;
-    CHK(hipEventElapsedTime(&ms, e0, e1));
-    // wave-instructions per SIMD = wps * iters * ops_per_iter ; cycles at 2.4 GHz
-    const double instr = (double)wps * iters * ops_per_iter;
-    const double cyc = ms * 1e-3 * 2.4e9;
-    printf("  wps=%d: %.2f cyc/instr (%.3f ms)", wps, cyc / instr, ms);
+    CHK(hipMemcpy(st.data(), stamps_d, sizeof(unsigned long long) * 2 * nwaves, hipMemcpyDeviceToHost));
+    std::vector<double> cyc(nwaves), mhz(nwaves);
+    for (int w = 0; w < nwaves; w++) {
+      cyc[w] = (double)st[2 * w];
+      mhz[w] = (double)st[2 * w] / (double)st[2 * w + 1] * 100.0;
+    }
+    std::sort(cyc.begin(), cyc.end());
+    std::sort(mhz.begin(), mhz.end());
+    // cycles per wave-instruction per SIMD = wave lifetime / (instructions it issued * waves sharing the SIMD)
+    printf(" | wps%d %5.2f cyc @%4.0f MHz", wps, cyc[nwaves / 2] / ((double)iters * per_iter * wps), mhz[nwaves / 2]);
   }
   printf("\n");
   return 0;
@@ -83,16 +157,26 @@ template <int KIND> int run(const char* name, int ops_per_iter, float* out) {
 
 int main() {
   float* out;
-  CHK(hipMalloc(&out, 256 * 8 * 256 * 4 * 2));
+  unsigned long long* stamps;
+  CHK(hipMalloc(&out, 4096));
+  CHK(hipMalloc(&stamps, sizeof(unsigned long long) * 2 * 512 * 16));
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, 0));
-  printf("device %s, %d CUs, clock %d kHz (cycles below assume 2.4 GHz)\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
-  run<0>("v_add_f32 x8", 8, out);
-  run<1>("v_pk_add_f32 x4 (8 adds)", 4, out);
-  run<2>("v_mul_f32 x8", 8, out);
-  run<3>("v_cmp_lt_f32->sgpr x8", 8, out);
-  run<4>("v_add_f64 x8", 8, out);
-  run<5>("v_subrev_f32 sgpr x8", 8, out);
-  run<6>("v_mbcnt lo/hi x8", 8, out);
+  printf("device %s, %d CUs. cycles = shader cycles (s_memtime) per wave-instruction per SIMD; MHz = clock held\n",
+         prop.gcnArchName, prop.multiProcessorCount);
+  run<0>("v_add_f32", 64, out, stamps);
+  run<4>("v_fma_f32", 64, out, stamps);
+  run<1>("v_pk_add_f32", 64, out, stamps);
+  run<2>("v_pk_mul_f32", 64, out, stamps);
+  run<3>("v_pk_fma_f32", 64, out, stamps);
+  run<10>("v_subrev_f32 (sgpr src)", 64, out, stamps);
+  run<5>("v_cmp_lt_f32 -> vcc", 64, out, stamps);
+  run<6>("v_cmp_lt_f32 -> sgpr pair", 64, out, stamps);
+  run<7>("v_cmp_lt_i32 sgpr src -> sgpr", 64, out, stamps);
+  run<8>("v_add_f64", 64, out, stamps);
+  run<9>("v_mul_f64", 64, out, stamps);
+  run<11>("test body today (8 instr) /test", 8, out, stamps);
+  run<12>("test body unpacked (10 instr) /test", 8, out, stamps);
+  run<13>("test body 2i packed (12 instr) /2tests", 8, out, stamps);
   return 0;
 }
