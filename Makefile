@@ -10,7 +10,8 @@ LIBDIR := md_neighbor_list_amd/lib
 CSRC := md_neighbor_list_amd/csrc
 
 # -ffp-contract=off: r2 = (dx*dx + dy*dy) + dz*dz must not be contracted into FMAs (bit-exact pair set).
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result
+# -fno-slp-vectorize: v_pk_add/mul_f32 issue slower than two plain ops on gfx950 (profiles/r01_valu_microbench.txt)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-result
 
 all: lib inputs tools oracle
 

@@ -129,6 +129,9 @@ int nl_get_mesh(nl_handle_t h, int32_t mesh[3], int64_t* ncell);
  * for F64); sorted_row[n] = input index of each sorted slot. */
 int nl_get_sorted(nl_handle_t h, const int32_t** cell_start_dev, const void** sorted_pos_dev,
                   const int32_t** sorted_row_dev, int64_t* ncell_local);
+/* Diagnostic cycle accumulators of the kernels (filled only when NL_DEBUG_FLAGS & 4 is set in the environment). */
+int nl_debug_read(nl_handle_t h, uint64_t* out, int32_t n, int reset);
+int nl_debug_occupancy(int32_t out[8]); /* LDS per CU/block (KiB), occupancy API answers, LDS bytes, registers */
 int nl_last_error(nl_handle_t h);     /* status of the last failed call on this handle */
 int nl_last_hip_error(nl_handle_t h); /* raw hipError_t behind the last NL_ERR_HIP */
 

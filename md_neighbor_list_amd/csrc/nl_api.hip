@@ -45,6 +45,11 @@ struct nl_handle_s {
   int32_t* count = nullptr;
   int32_t* key_pointer = nullptr;
   int32_t* progress = nullptr;
+  int32_t* base_sorted = nullptr;  // key_pointer of every sorted slot (persistent sweep)
+  int sweep_variant = 1;           // 1: one workgroup per cell (k_sweep); 2: persistent + LDS-DMA (k_sweep_p, fp32)
+  int num_cus = 256;
+  unsigned long long* dbg_buf = nullptr;
+  int dbg_flags = 0, dbg_wg_per_cu = 4;  // diagnostics (NL_DEBUG_FLAGS, NL_DEBUG_WG_PER_CU)
   int32_t* cell_count = nullptr;  // [ncell] followed by the status word
   int32_t* cell_start = nullptr;  // [ncell + 1]
   int64_t* block_sum = nullptr;
@@ -144,12 +149,23 @@ int launch_scan(nl_handle_t h, const int32_t* in, int64_t n, int32_t* out, int64
   return NL_OK;
 }
 
+FastDiv fastdiv_make(uint32_t d) {  // see fastdiv() in nl_kernels.hpp; valid for dividends below 2^31
+  FastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) s++;
+  f.s = s;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  return f;
+}
+
 template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   SweepArgs<T> a;
   a.sorted = static_cast<const Pos<T>*>(h->sorted);
   a.sorted_row = h->sorted_row;
   a.cell_start = h->cell_start;
   a.mx = h->m[0], a.my = h->m[1], a.mzl = h->b_mzl, a.slab = h->b_slab;
+  a.div_mx = fastdiv_make((uint32_t)h->m[0]), a.div_my = fastdiv_make((uint32_t)h->m[1]);
   a.rc2 = sizeof(T) == 4 ? (T)h->rc2_f : (T)h->rc2;
   a.count = h->count;
   a.progress = h->progress;
@@ -158,6 +174,8 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.total = h->totals + 1;
   a.capacity = h->capacity;
   a.status = h->status;
+  a.dbg = h->dbg_flags;
+  a.dbg_buf = h->dbg_buf;
   return a;
 }
 
@@ -165,9 +183,30 @@ template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) 
   const int32_t owned_layers = h->b_slab ? h->b_mzl - 2 : h->b_mzl;
   const int32_t ncells_i = h->m[0] * h->m[1] * owned_layers;
   const SweepArgs<T> a = sweep_args<T>(h);
-  if (mode == MODE_COUNT)
-    hipLaunchKernelGGL((k_sweep<T, MODE_COUNT>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
-  else
+  if constexpr (sizeof(T) == 4) {
+    if (h->sweep_variant == 2) {
+      // persistent kernel: 4 workgroups of 8 waves per CU (2 x 20 KiB LDS each), each walking a run of cells
+      const int32_t grid = std::max(8, std::min(h->dbg_wg_per_cu * h->num_cus, (ncells_i + 1) / 2 / 8 * 8));
+      if (mode == MODE_COUNT) {
+        hipLaunchKernelGGL((k_sweep_p<T, MODE_COUNT>), dim3(grid), dim3(PW * WAVE), 0, s, a, ncells_i, nullptr,
+                           h->cell_count + h->ncell + 1);
+      } else {
+        const int32_t nbp = (h->n + 255) / 256;
+        if (h->n > 0)
+          hipLaunchKernelGGL(k_row_base, dim3(nbp), dim3(256), 0, s, h->key_pointer, h->sorted_row, h->n_rows, h->n,
+                             h->base_sorted);
+        hipLaunchKernelGGL((k_sweep_p<T, MODE_FILL>), dim3(grid), dim3(PW * WAVE), 0, s, a, ncells_i, h->base_sorted,
+                           h->cell_count + h->ncell + 1 + 8);
+      }
+      return;
+    }
+  }
+  if (mode == MODE_COUNT) {
+    if constexpr (sizeof(T) == 4)
+      hipLaunchKernelGGL(k_sweep_count_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_sweep<T, MODE_COUNT>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+  } else
     hipLaunchKernelGGL((k_sweep<T, MODE_FILL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
 }
 
@@ -183,7 +222,8 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   const T* q = static_cast<const T*>(q_dev);
 
   // cell histogram and the status word are one allocation: one memset node
-  HIPCHK(h, hipMemsetAsync(h->cell_count, 0, sizeof(int32_t) * (size_t)(h->ncell + 1), s));
+  // ... followed by the 16 cell tickets of the two persistent sweeps
+  HIPCHK(h, hipMemsetAsync(h->cell_count, 0, sizeof(int32_t) * (size_t)(h->ncell + 1 + 16), s));
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
   if (n > 0) hipLaunchKernelGGL((k_hash<T>), dim3(nbp), dim3(256), 0, s, q, stride, n, g, h->cell_count, h->rank, h->status);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_CELL_SCAN], s));
@@ -326,6 +366,13 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
       return NL_ERR_HIP;
     }
   memset(h->host, 0, sizeof(HostResult));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
+    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) == 2 ? 2 : 1;
+    if (const char* v = getenv("NL_DEBUG_FLAGS")) h->dbg_flags = atoi(v);
+    if (const char* v = getenv("NL_DEBUG_WG_PER_CU")) h->dbg_wg_per_cu = std::max(1, atoi(v));
+  }
   *out = h;
   return NL_OK;
 }
@@ -334,7 +381,7 @@ int nl_destroy(nl_handle_t h) {
   if (!h) return NL_ERR_ARG;
   (void)hipSetDevice(h->device);
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
-  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->count, h->key_pointer, h->progress, h->cell_count,
+  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->count, h->key_pointer, h->progress, h->base_sorted, h->dbg_buf, h->cell_count,
                   h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -363,14 +410,17 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   if ((rc = dev_alloc(h, &h->count, 4 * (n + 32)))) return rc;
   if ((rc = dev_alloc(h, &h->key_pointer, 4 * (n + 32)))) return rc;
   if ((rc = dev_alloc(h, &h->progress, 4 * (n + 16)))) return rc;
-  if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->base_sorted, 4 * (n + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->dbg_buf, 8 * (64 + 4 * 4096)))) return rc;
+  HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
+  if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64)))) return rc;
   if ((rc = dev_alloc(h, &h->cell_start, 4 * ((size_t)h->ncell + 32)))) return rc;
   const size_t nblk = std::max<size_t>(n, (size_t)h->ncell) / SCAN_BLOCK + 2;
   if ((rc = dev_alloc(h, &h->block_sum, 8 * nblk))) return rc;
   if ((rc = dev_alloc(h, &h->totals, 8 * 4))) return rc;
   h->status = reinterpret_cast<uint32_t*>(h->cell_count + h->ncell);  // cleared by the same memset as the histogram
   HIPCHK(h, hipMemset(h->totals, 0, 32));
-  HIPCHK(h, hipMemset(h->cell_count, 0, 4 * ((size_t)h->ncell + 16)));
+  HIPCHK(h, hipMemset(h->cell_count, 0, 4 * ((size_t)h->ncell + 64)));
   h->n_max = n_max;
   if (!h->capacity_user) {
     // ideal-gas estimate of the half-pair count: N * rho * (2/3) pi rc^3, with 30 % head room
@@ -487,6 +537,36 @@ int nl_get_sorted(nl_handle_t h, const int32_t** cell_start_dev, const void** so
   if (sorted_pos_dev) *sorted_pos_dev = h->sorted;
   if (sorted_row_dev) *sorted_row_dev = h->sorted_row;
   if (ncell_local) *ncell_local = h->ncell_local;
+  return NL_OK;
+}
+
+int nl_debug_read(nl_handle_t h, uint64_t* out, int32_t n, int reset) {
+  if (!h || !out || !h->dbg_buf || n < 0 || n > 64 + 4 * 4096) return NL_ERR_ARG;
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(out, h->dbg_buf, 8 * (size_t)n, hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
+  return NL_OK;
+}
+
+int nl_debug_occupancy(int32_t out[8]) {
+  if (!out) return NL_ERR_ARG;
+  int v = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return NL_ERR_NO_DEVICE;
+  out[0] = (int32_t)(prop.maxSharedMemoryPerMultiProcessor / 1024);
+  out[1] = (int32_t)(prop.sharedMemPerBlock / 1024);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_p<float, MODE_COUNT>, PW * WAVE, 0);
+  out[2] = v;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_p<float, MODE_FILL>, PW * WAVE, 0);
+  out[3] = v;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_count_f32, SWEEP_WAVES * WAVE, 0);
+  out[4] = v;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep<float, MODE_FILL>, SWEEP_WAVES * WAVE, 0);
+  out[5] = v;
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_sweep_p<float, MODE_COUNT>));
+  out[6] = (int32_t)fa.sharedSizeBytes;
+  out[7] = fa.numRegs;
   return NL_OK;
 }
 

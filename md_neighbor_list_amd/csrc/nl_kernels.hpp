@@ -158,6 +158,17 @@ __device__ __forceinline__ int32_t wave_incl_scan(int32_t v, int lane) {
   }
   return v;
 }
+// Inclusive scan over lanes 0..31 with DPP row shifts (no LDS traffic, 5 VALU instructions): shr 1,2,4,8 inside
+// each row of 16 lanes, then row_bcast:15 carries row 0's total into row 1.  Lanes >= 32 are not meaningful.
+__device__ __forceinline__ int32_t scan32_dpp(int32_t v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  return v;
+}
+
 __device__ __forceinline__ int64_t wave_incl_scan64(int64_t v, int lane) {
 #pragma unroll
   for (int d = 1; d < WAVE; d <<= 1) {
@@ -285,11 +296,23 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
 // so lane j is accepted only if gid_j > gid_i; that also drops j == i.
 enum { MODE_COUNT = 0, MODE_FILL = 1 };
 
+// n / d for 0 <= n < 2^31 and a divisor fixed at launch: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery
+// round-up form), evaluated without the 33-bit overflow.  The host fills m and s (fastdiv_make in nl_api.hip).
+struct FastDiv {
+  uint32_t d, m, s;
+};
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  const uint32_t t = __umulhi(n, f.m);
+  return (t + ((n - t) >> 1)) >> (f.s - 1);
+}
+
 template <typename T> struct SweepArgs {
   const Pos<T>* __restrict__ sorted;
   const int32_t* __restrict__ sorted_row;
   const int32_t* __restrict__ cell_start;
   int32_t mx, my, mzl, slab;
+  FastDiv div_mx, div_my;         // i-cell index -> (cx, cy, cz) without integer division
   T rc2;                          // largest T value <= rc*rc in double, so !(r2 > rc2) == !((double)r2 > rc2_double)
   int32_t* __restrict__ count;    // [n_rows] number_of_partners (COUNT writes, FILL reads nothing from it)
   int32_t* __restrict__ progress; // [n_rows] scratch, only touched when a stencil needs more than one LDS batch
@@ -298,25 +321,27 @@ template <typename T> struct SweepArgs {
   const int64_t* __restrict__ total;
   int64_t capacity;
   uint32_t* __restrict__ status;
+  unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
+  int32_t dbg;  // diagnostics only (NL_DEBUG_FLAGS): 1 = skip the search, 2 = skip the staging copy; 0 in production
 };
 
 template <typename T> struct SweepCfg;
-template <> struct SweepCfg<float> { static constexpr int CAP = 1536; };   // 24 KB of LDS
+template <> struct SweepCfg<float> { static constexpr int CAP = 1280; };   // 20 KB of LDS: 8 workgroups = 32 waves per CU
 template <> struct SweepCfg<double> { static constexpr int CAP = 1024; };  // 32 KB of LDS
 
-constexpr int SWEEP_WAVES = 2;
-constexpr int SWEEP_G = 8;
+constexpr int SWEEP_WAVES = 4;
+constexpr int SWEEP_G = 6;
 constexpr int NSEG = 18;
 
-// One group of GC (compile-time, 1..8) i-particles against the nj staged j-particles.
+// One group of GC (compile-time, 1..6) i-particles against the nj staged j-particles.
 // pi_l / base_l: lane k < GC holds i-particle k and the list offset of its row.  Returns, in lane k, the number
 // of accepted partners of i-particle k.  All per-i state is wave-uniform (SGPRs): position, id, running count.
 template <typename T, int MODE, int GC>
 __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos<T>* tile, int32_t nj,
                                                 int32_t ntiles, int lane, const Pos<T>& pi_l, int32_t base_l) {
   T xi[GC], yi[GC], zi[GC];
-  int32_t gi[GC], cnt[GC];
-  uint32_t base[GC];
+  int32_t gi[GC];
+  uint32_t cur[GC];  // COUNT: hits so far; FILL: list offset of the row + hits so far
 #pragma unroll
   for (int k = 0; k < GC; k++) {
     if constexpr (sizeof(T) == 4) {
@@ -329,51 +354,63 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
       zi[k] = __shfl(pi_l.z, k, WAVE);
     }
     gi[k] = __builtin_amdgcn_readlane(pi_l.gid, k);
-    base[k] = (uint32_t)__builtin_amdgcn_readlane(base_l, k);
-    cnt[k] = 0;
+    cur[k] = MODE == MODE_FILL ? (uint32_t)__builtin_amdgcn_readlane(base_l, k) : 0u;
   }
 
-  Pos<T> cur = tile[lane];
-  if (lane >= nj) cur.gid = INT32_MIN;  // tail lanes can never satisfy gid_j > gid_i
-  for (int32_t t = 0; t < ntiles; t++) {
-    Pos<T> nxt = cur;
-    if (t + 1 < ntiles) {
-      const int32_t jn = (t + 1) * WAVE + lane;
-      nxt = tile[jn];
-      if (jn >= nj) nxt.gid = INT32_MIN;
+  // One tile of 64 staged j-particles (lanes) against the GC i-particles (SGPRs).  All vector work of the GC
+  // tests comes first (masks land in SGPR pairs), the scalar bookkeeping afterwards: a scalar instruction that
+  // consumes a v_cmp result stalls the wave until the compare has left the VALU.
+  auto test_tile = [&](const Pos<T>& pj) {
+    uint64_t mask[GC];
+    bool hit[GC];  // per-lane predicate: lives in an SGPR pair as a lane mask, costs no VALU
+#pragma unroll
+    for (int k = 0; k < GC; k++) {
+      const T dx = sub_rn(pj.x, xi[k]), dy = sub_rn(pj.y, yi[k]), dz = sub_rn(pj.z, zi[k]);
+      const T r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+      const bool in_range = !(r2 > a.rc2), upper = pj.gid > gi[k];
+      hit[k] = in_range && upper;
+      mask[k] = __builtin_amdgcn_ballot_w64(in_range) & __builtin_amdgcn_ballot_w64(upper);
     }
 #pragma unroll
     for (int k = 0; k < GC; k++) {
-      const T dx = sub_rn(cur.x, xi[k]), dy = sub_rn(cur.y, yi[k]), dz = sub_rn(cur.z, zi[k]);
-      const T r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-      // two direct compares -> two SGPR masks -> s_and: no VALU spent on forming the ballot
-      const bool in_range = !(r2 > a.rc2), upper = cur.gid > gi[k];
-      const uint64_t mask = __builtin_amdgcn_ballot_w64(in_range) & __builtin_amdgcn_ballot_w64(upper);
       if (MODE == MODE_FILL) {
-        if (in_range && upper) {
-          const uint32_t pre =
-              __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-          // uniform 64-bit base + 32-bit byte offset (global_store saddr form); the host keeps capacity < 2^30
-          const uint32_t boff = (base[k] + (uint32_t)cnt[k] + pre) << 2;
-          *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + boff) = cur.gid;
+        if (hit[k]) {
+          const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[k] >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)mask[k], 0u));
+          // uniform 64-bit base + 32-bit byte offset (global_store saddr form); the host keeps capacity < 2^30.
+          // cur[k] = list offset of the row + entries written so far
+          const uint32_t boff = (cur[k] + pre) << 2;
+          *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + boff) = pj.gid;
         }
       }
-      cnt[k] += __popcll(mask);
+      cur[k] += (uint32_t)__popcll(mask[k]);
     }
-    cur = nxt;
+  };
+
+  // The staged stream is padded to a whole tile with sentinels (gid = INT32_MIN can never satisfy
+  // gid_j > gid_i), so tiles need no per-lane tail handling.  Two register sets in ping-pong: the ds_read of the
+  // next tile is in flight while the current one is tested, and no register copies are needed.
+  const int32_t last = (ntiles - 1) * WAVE + lane;
+  Pos<T> pa = tile[lane], pb;
+  int32_t t = 0;
+  for (; t + 1 < ntiles; t += 2) {  // both tests unconditional, so neither load can be sunk next to its use
+    pb = tile[(t + 1) * WAVE + lane];
+    test_tile(pa);
+    pa = tile[min((t + 2) * WAVE + lane, last)];
+    test_tile(pb);
   }
-  int32_t mine = 0;
+  if (t < ntiles) test_tile(pa);
+  uint32_t mine = 0;
 #pragma unroll
-  for (int k = 0; k < GC; k++) mine = lane == k ? cnt[k] : mine;
-  return mine;
+  for (int k = 0; k < GC; k++) mine = lane == k ? cur[k] : mine;
+  return (int32_t)(MODE == MODE_FILL ? mine - (uint32_t)base_l : mine);
 }
 
 template <typename T, int MODE>
-__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
+__device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   constexpr int CAP = SweepCfg<T>::CAP;
-  constexpr int NT = SWEEP_WAVES * WAVE;
   constexpr int G = SWEEP_G;
-  static_assert(G == 8, "search_group dispatch covers group sizes 1..8");
+  static_assert(G == 6, "search_group dispatch covers group sizes 1..6");
   __shared__ Pos<T> tile[CAP];
 
   if (MODE == MODE_FILL) {
@@ -392,15 +429,17 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
     const int32_t nb = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nb >> 3, r = nb & 7;
     w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  const int32_t cx = w % a.mx, cy = (w / a.mx) % a.my, cz = w / (a.mx * a.my) + (a.slab ? 1 : 0);
+  const int32_t wy = (int32_t)fastdiv((uint32_t)w, a.div_mx), cx = w - wy * a.mx;
+  const int32_t wz = (int32_t)fastdiv((uint32_t)wy, a.div_my), cy = wy - wz * a.my, cz = wz + (a.slab ? 1 : 0);
   const int32_t c = cx + (cy + cz * a.my) * a.mx;
   const int32_t ibeg = a.cell_start[c], ni = a.cell_start[c + 1] - ibeg;
-  if (ni == 0) return;
 
+  // (the empty-cell exit comes after the segment-table loads so that both round trips are in flight together)
   // Segment table, one segment per lane (lanes >= 18 hold empty segments): 9 (dz,dy) rows x 2 x-parts.
   int32_t seg_src = 0, seg_len = 0;
   if (lane < NSEG) {
-    const int32_t s = lane >> 1, part = lane & 1, dz = s / 3 - 1, dy = s % 3 - 1;
+    // slots 0..8 = first x-part of the nine (dz,dy) rows (never empty in the interior), 9..17 = the wrapped part
+    const int32_t s = lane % 9, part = lane / 9, dz = s / 3 - 1, dy = s % 3 - 1;
     int32_t y = cy + dy, z = cz + dz;
     if (y < 0) y += a.my;
     if (y >= a.my) y -= a.my;
@@ -420,11 +459,12 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
     seg_src = a.cell_start[rowbase + x0];
     seg_len = a.cell_start[rowbase + x1] - seg_src;
   }
-  const int32_t seg_off = wave_incl_scan(seg_len, lane) - seg_len;  // exclusive offsets in the staged stream
+  if (ni == 0) return;
+  const int32_t seg_off = scan32_dpp(seg_len) - seg_len;  // exclusive offsets in the staged stream
   const int32_t total_j = __builtin_amdgcn_readlane(seg_off + seg_len, NSEG - 1);
   const int32_t nbatch = (total_j + CAP - 1) / CAP;
 
-  // i-groups: `rounds` groups per wave, sized so that both waves get the same number of groups.
+  // i-groups: `rounds` groups per wave, sized so that all waves get the same number of groups.
   const int32_t rounds = (ni + SWEEP_WAVES * G - 1) / (SWEEP_WAVES * G);
   const int32_t ngroups = rounds * SWEEP_WAVES;
   const int32_t gsize = (ni + ngroups - 1) / ngroups;
@@ -433,46 +473,30 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
     const int32_t win0 = batch * CAP;
     const int32_t nj = min(total_j - win0, CAP);
     if (batch) __syncthreads();  // everyone is done reading the previous batch
-    // ---- stage: copy the stream window [win0, win0 + nj) into LDS, 6 segments' loads in flight at a time.
-    // Loads are unconditional (clamped to a valid slot) so that they issue back to back; only the LDS write
-    // is predicated.
-#pragma unroll
-    for (int s0 = 0; s0 < NSEG; s0 += 6) {
-      Pos<T> v0, v1, v2, v3, v4, v5;
-      int32_t d0, d1, d2, d3, d4, d5;
-#define NL_STAGE_LOAD(u, v, d)                                                          \
-  {                                                                                     \
-    const int32_t src = __builtin_amdgcn_readlane(seg_src, s0 + u);                     \
-    const int32_t len = __builtin_amdgcn_readlane(seg_len, s0 + u);                     \
-    const int32_t off = __builtin_amdgcn_readlane(seg_off, s0 + u);                     \
-    const int32_t dd = off + tid - win0;                                                \
-    const bool ok = tid < len && (uint32_t)dd < (uint32_t)CAP;                          \
-    d = ok ? dd : -1;                                                                   \
-    v = a.sorted[ok ? src + tid : ibeg];                                                \
-  }
-      NL_STAGE_LOAD(0, v0, d0)
-      NL_STAGE_LOAD(1, v1, d1)
-      NL_STAGE_LOAD(2, v2, d2)
-      NL_STAGE_LOAD(3, v3, d3)
-      NL_STAGE_LOAD(4, v4, d4)
-      NL_STAGE_LOAD(5, v5, d5)
-#undef NL_STAGE_LOAD
-      if (d0 >= 0) tile[d0] = v0;
-      if (d1 >= 0) tile[d1] = v1;
-      if (d2 >= 0) tile[d2] = v2;
-      if (d3 >= 0) tile[d3] = v3;
-      if (d4 >= 0) tile[d4] = v4;
-      if (d5 >= 0) tile[d5] = v5;
+    // ---- stage: copy the stream window [win0, win0 + nj) into LDS.  The waves share the segments (slot s goes
+    // to wave s mod 4: the nine never-empty slots spread 3/2/2/2); a wave copies a segment 128 particles at a
+    // time with both 16-byte loads in flight before the LDS writes.
+    for (int32_t sg = wave; sg < NSEG; sg += SWEEP_WAVES) {
+      const int32_t len = __builtin_amdgcn_readlane(seg_len, sg);
+      if (len == 0) continue;
+      const int32_t src = __builtin_amdgcn_readlane(seg_src, sg);
+      const int32_t off = __builtin_amdgcn_readlane(seg_off, sg) - win0;
+      for (int32_t k = lane; k < len; k += 2 * WAVE) {
+        const int32_t k1 = k + WAVE;
+        const bool p1 = k1 < len;
+        const Pos<T> v0 = a.sorted[src + k];
+        const Pos<T> v1 = a.sorted[src + (p1 ? k1 : k)];
+        if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) tile[off + k] = v0;
+        if (p1 && (nbatch == 1 || (uint32_t)(off + k1) < (uint32_t)CAP)) tile[off + k1] = v1;
+      }
     }
-    // long segments (more than NT particles): the rest, one stride at a time
-    for (int s = 0; s < NSEG; s++) {
-      const int32_t len = __builtin_amdgcn_readlane(seg_len, s);
-      if (len <= NT) continue;
-      const int32_t src = __builtin_amdgcn_readlane(seg_src, s);
-      const int32_t off = __builtin_amdgcn_readlane(seg_off, s);
-      for (int32_t k = tid + NT; k < len; k += NT) {
-        const int32_t d = off + k - win0;
-        if ((uint32_t)d < (uint32_t)CAP) tile[d] = a.sorted[src + k];
+    {  // sentinel padding up to the next tile boundary
+      const int32_t pad = nj + tid;
+      if (pad < ((nj + WAVE - 1) & ~(WAVE - 1))) {
+        Pos<T> sentinel;
+        sentinel.x = 0, sentinel.y = 0, sentinel.z = 0, sentinel.gid = INT32_MIN;
+        if constexpr (sizeof(T) == 8) sentinel.row = 0;
+        tile[pad] = sentinel;
       }
     }
     __syncthreads();
@@ -500,9 +524,7 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
         case 3: mine = search_group<T, MODE, 3>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
         case 4: mine = search_group<T, MODE, 4>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
         case 5: mine = search_group<T, MODE, 5>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
-        case 6: mine = search_group<T, MODE, 6>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
-        case 7: mine = search_group<T, MODE, 7>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
-        default: mine = search_group<T, MODE, 8>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+        default: mine = search_group<T, MODE, 6>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
       }
       if (lane < gcount) {
         if (nbatch > 1) {
@@ -516,4 +538,17 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
   }
 }
 
+template <typename T, int MODE> __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
+  sweep_cell<T, MODE>(a);
+}
+// The fp32 COUNT pass is held to 80 SGPRs: the SGPR file admits 8 waves per SIMD only up to 80 per wave (6 at the
+// 102 the compiler takes by itself).  FILL needs the extra SGPRs (cursors + masks): capped, it spills into its
+// inner loop and loses more than the occupancy gains.
+__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
+k_sweep_count_f32(SweepArgs<float> a) {
+  sweep_cell<float, MODE_COUNT>(a);
+}
+
 }  // namespace nl
+
+#include "nl_sweep_p.hpp"

@@ -29,6 +29,7 @@ run() {  # run <seconds> <logfile> cmd...
 for s in $STEPS; do
   case $s in
     smoke) run 300 "$OUT/smoke.log" python -c "import __graft_entry__ as g; g.smoke()"; tail -3 "$OUT/smoke.log" ;;
+    sbench) run 120 "$OUT/search_bench.log" ./tools/search_bench; cat "$OUT/search_bench.log" ;;
     micro) run 120 "$OUT/microbench.log" ./tools/microbench; cat "$OUT/microbench.log" ;;
     tests) run 900 "$OUT/pytest_gpu.log" python -m pytest tests -m gpu -q -x --durations=8; tail -25 "$OUT/pytest_gpu.log" ;;
     bench) run 420 "$OUT/bench.log" python bench.py --steps 50 --warmup 5; tail -3 "$OUT/bench.log" ;;
@@ -38,11 +39,13 @@ for s in $STEPS; do
       run 420 "$OUT/rocprof_stats.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline
       find "$OUT/prof" -name "*kernel_stats.csv" -exec cat {} \; | head -30 ;;
     pmc)
-      rm -rf "$OUT/pmc_r" "$OUT/pmc_w" "$OUT/pmc_sq"
-      run 420 "$OUT/pmc_r.log" rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_r" -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --profile-reps 1 &&
-      run 420 "$OUT/pmc_w.log" rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --profile-reps 1 &&
-      run 420 "$OUT/pmc_sq.log" rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --profile-reps 1
-      python tools/summarize_pmc.py "$OUT" > "$OUT/pmc_summary.txt" 2>&1; cat "$OUT/pmc_summary.txt" ;;
+      rm -rf "$OUT/pmc_r" "$OUT/pmc_w" "$OUT/pmc_sq" "$OUT/pmc_sq2"
+      PB="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --profile-reps 1"
+      run 420 "$OUT/pmc_r.log" rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_r" -- $PB &&
+      run 420 "$OUT/pmc_w.log" rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_w" -- $PB &&
+      run 420 "$OUT/pmc_sq.log" rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq" -- $PB &&
+      run 420 "$OUT/pmc_sq2.log" rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_LEVEL_WAVES --output-format csv -d "$OUT/pmc_sq2" -- $PB
+      python tools/summarize_pmc.py "$OUT" --json "$OUT/pmc_summary.json" > "$OUT/pmc_summary.txt" 2>&1; grep -A40 "k_sweep" "$OUT/pmc_summary.txt" ;;
     *) echo "unknown step $s" ;;
   esac
 done

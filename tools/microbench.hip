@@ -95,22 +95,48 @@ __global__ void __launch_bounds__(1024) k(float* out, unsigned long long* stamps
                "v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %2\n v_cmp_lt_i32 %7, %6, %3\n v_cmp_nlt_f32 %8, %6, %0\n"
                : "=&v"(a4), "=&v"(a5), "=&v"(a6)
                : "v"(a0), "v"(a1), "v"(a2), "s"(sb), "s"(m0), "s"(m1));)
+    } else if (KIND == 14) {  // unpacked test + the scalar bookkeeping of the count pass (s_and, s_bcnt1, s_add)
+      REP8(asm volatile(
+               "v_subrev_f32 v40, s40, v46\n v_subrev_f32 v41, s41, v47\n v_subrev_f32 v42, s42, v48\n"
+               "v_mul_f32 v40, v40, v40\n v_mul_f32 v41, v41, v41\n v_mul_f32 v42, v42, v42\n"
+               "v_add_f32 v40, v40, v41\n v_add_f32 v40, v40, v42\n"
+               "v_cmp_lt_i32 s[52:53], s47, v52\n v_cmp_nlt_f32 vcc, s46, v40\n"
+               "s_and_b64 s[48:49], s[52:53], vcc\n s_bcnt1_i32_b64 s50, s[48:49]\n s_add_i32 s51, s51, s50\n"
+               ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "s48", "s49", "s50", "s51", "s52", "s53", "vcc", "scc");)
+    } else if (KIND == 15) {  // same, bookkeeping delayed by one test (consume the PREVIOUS test's masks)
+      REP8(asm volatile(
+               "v_subrev_f32 v40, s40, v46\n v_subrev_f32 v41, s41, v47\n v_subrev_f32 v42, s42, v48\n"
+               "s_and_b64 s[48:49], s[52:53], s[54:55]\n"
+               "v_mul_f32 v40, v40, v40\n v_mul_f32 v41, v41, v41\n v_mul_f32 v42, v42, v42\n"
+               "s_bcnt1_i32_b64 s50, s[48:49]\n"
+               "v_add_f32 v40, v40, v41\n v_add_f32 v40, v40, v42\n"
+               "s_add_i32 s51, s51, s50\n"
+               "v_cmp_lt_i32 s[52:53], s47, v52\n v_cmp_nlt_f32 s[54:55], s46, v40\n"
+               ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "scc");)
+    } else if (KIND == 16) {  // per-lane counting: no scalar ops at all (cndmask + cmp + addc), 11 VALU per test
+      REP8(asm volatile(
+               "v_subrev_f32 v40, s40, v46\n v_subrev_f32 v41, s41, v47\n v_subrev_f32 v42, s42, v48\n"
+               "v_mul_f32 v40, v40, v40\n v_mul_f32 v41, v41, v41\n v_mul_f32 v42, v42, v42\n"
+               "v_add_f32 v40, v40, v41\n v_add_f32 v40, v40, v42\n"
+               "v_cmp_nlt_f32 vcc, s46, v40\n v_cndmask_b32 v43, v53, v52, vcc\n v_cmp_lt_i32 vcc, s47, v43\n"
+               "v_addc_co_u32 v44, vcc, 0, v44, vcc\n"
+               ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "vcc");)
     } else if (KIND == 13) {  // two tests per pass in packed form: 2 i-particles (SGPR pairs) against the same j
       // 8 packed + 4 compares for 2 tests = 6 instructions per test; fixed registers (timing only)
       REP8(asm volatile(
-               "v_pk_add_f32 v[100:101], v[110:111], s[40:41] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
-               "v_pk_add_f32 v[102:103], v[112:113], s[42:43] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
-               "v_pk_add_f32 v[104:105], v[114:115], s[44:45] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
-               "v_pk_mul_f32 v[100:101], v[100:101], v[100:101]\n"
-               "v_pk_mul_f32 v[102:103], v[102:103], v[102:103]\n"
-               "v_pk_mul_f32 v[104:105], v[104:105], v[104:105]\n"
-               "v_pk_add_f32 v[100:101], v[100:101], v[102:103]\n"
-               "v_pk_add_f32 v[100:101], v[100:101], v[104:105]\n"
-               "v_cmp_lt_i32 s[52:53], s47, v116\n"
-               "v_cmp_lt_i32 s[54:55], s56, v116\n"
-               "v_cmp_nlt_f32 s[48:49], s46, v100\n"
-               "v_cmp_nlt_f32 s[50:51], s46, v101\n"
-               ::: "v100", "v101", "v102", "v103", "v104", "v105", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55");)
+               "v_pk_add_f32 v[40:41], v[46:47], s[40:41] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+               "v_pk_add_f32 v[42:43], v[48:49], s[42:43] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+               "v_pk_add_f32 v[44:45], v[50:51], s[44:45] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n"
+               "v_pk_mul_f32 v[40:41], v[40:41], v[40:41]\n"
+               "v_pk_mul_f32 v[42:43], v[42:43], v[42:43]\n"
+               "v_pk_mul_f32 v[44:45], v[44:45], v[44:45]\n"
+               "v_pk_add_f32 v[40:41], v[40:41], v[42:43]\n"
+               "v_pk_add_f32 v[40:41], v[40:41], v[44:45]\n"
+               "v_cmp_lt_i32 s[52:53], s47, v52\n"
+               "v_cmp_lt_i32 s[54:55], s56, v52\n"
+               "v_cmp_nlt_f32 s[48:49], s46, v40\n"
+               "v_cmp_nlt_f32 s[50:51], s46, v41\n"
+               ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55");)
     }
   }
   asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
@@ -128,28 +154,26 @@ template <int KIND> int run(const char* name, int per_iter, float* out, unsigned
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
-  const int iters = 4000;
+  const int iters = 3000;
   CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  printf("%-34s", name);
-  for (int wps : {1, 2, 4, 8}) {
-    const int threads = wps >= 4 ? 1024 : 256 * wps;
-    const int blocks = wps == 8 ? 2 * cus : cus;
-    const size_t lds = wps == 8 ? 80 * 1024 : 160 * 1024;
+  printf("%-36s", name);
+  // (threads per block, blocks per CU): LDS per block = 160 KiB / blocks pins exactly that many blocks on a CU
+  const int cfg[][2] = {{256, 1}, {256, 2}, {256, 4}, {256, 6}, {256, 8}, {1024, 1}, {1024, 2}, {512, 4}};
+  for (auto& c : cfg) {
+    const int threads = c[0], bpc = c[1];
+    const int wps = threads / 256 * bpc;
+    const int blocks = cus * bpc;
+    const size_t lds = (size_t)(160 * 1024 / bpc) & ~(size_t)1023;
     const int nwaves = blocks * threads / 64;
     std::vector<unsigned long long> st(2 * nwaves);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), lds, 0, out, stamps_d, 200, 1.0f);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), lds, 0, out, stamps_d, 100, 1.0f);
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), lds, 0, out, stamps_d, iters, 1.0f);
     CHK(hipDeviceSynchronize());
     CHK(hipMemcpy(st.data(), stamps_d, sizeof(unsigned long long) * 2 * nwaves, hipMemcpyDeviceToHost));
-    std::vector<double> cyc(nwaves), mhz(nwaves);
-    for (int w = 0; w < nwaves; w++) {
-      cyc[w] = (double)st[2 * w];
-      mhz[w] = (double)st[2 * w] / (double)st[2 * w + 1] * 100.0;
-    }
+    std::vector<double> cyc(nwaves);
+    for (int w = 0; w < nwaves; w++) cyc[w] = (double)st[2 * w];
     std::sort(cyc.begin(), cyc.end());
-    std::sort(mhz.begin(), mhz.end());
-    // cycles per wave-instruction per SIMD = wave lifetime / (instructions it issued * waves sharing the SIMD)
-    printf(" | wps%d %5.2f cyc @%4.0f MHz", wps, cyc[nwaves / 2] / ((double)iters * per_iter * wps), mhz[nwaves / 2]);
+    printf(" | %dx%d(w%d) %5.2f/%5.2f", bpc, threads, wps, cyc[nwaves / 2] / ((double)iters * per_iter * wps), cyc[nwaves - 1] / ((double)iters * per_iter * wps));
   }
   printf("\n");
   return 0;
@@ -159,10 +183,10 @@ int main() {
   float* out;
   unsigned long long* stamps;
   CHK(hipMalloc(&out, 4096));
-  CHK(hipMalloc(&stamps, sizeof(unsigned long long) * 2 * 512 * 16));
+  CHK(hipMalloc(&stamps, sizeof(unsigned long long) * 2 * 256 * 8 * 16));
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, 0));
-  printf("device %s, %d CUs. cycles = shader cycles (s_memtime) per wave-instruction per SIMD; MHz = clock held\n",
+  printf("device %s, %d CUs. cycles = shader cycles (s_memtime) per wave-instruction per SIMD, median/max over waves\n",
          prop.gcnArchName, prop.multiProcessorCount);
   run<0>("v_add_f32", 64, out, stamps);
   run<4>("v_fma_f32", 64, out, stamps);
@@ -178,5 +202,8 @@ int main() {
   run<11>("test body today (8 instr) /test", 8, out, stamps);
   run<12>("test body unpacked (10 instr) /test", 8, out, stamps);
   run<13>("test body 2i packed (12 instr) /2tests", 8, out, stamps);
+  run<14>("test + s_and,s_bcnt1,s_add /test", 8, out, stamps);
+  run<15>("test + delayed scalar ops /test", 8, out, stamps);
+  run<16>("test + per-lane count (12 VALU) /test", 8, out, stamps);
   return 0;
 }
