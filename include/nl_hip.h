@@ -157,7 +157,8 @@ int nl_profile_last_build(nl_handle_t h, int32_t reps, double ms[NL_NUM_STAGES])
 /* --------------------------------------------------------------------------------- buffers (cuda_ptr shim) */
 
 /* Back the reference's cuda_ptr<T> (cuda_ptr.cuh:11-112): a device buffer paired with a pinned host buffer. */
-int nl_buf_alloc(void** dev, void** host, size_t bytes);          /* allocate(), cuda_ptr.cuh:40-45        */
+int nl_buf_alloc(void** dev, void** host, size_t bytes);          /* allocate(), cuda_ptr.cuh:40-45; either
+                                                                     pointer may be NULL (that half is skipped) */
 int nl_buf_free(void* dev, void* host);                           /* deallocate(), cuda_ptr.cuh:107-111    */
 int nl_buf_h2d(void* dev, const void* host, size_t bytes);        /* host2dev(), cuda_ptr.cuh:47-53        */
 int nl_buf_d2h(void* host, const void* dev, size_t bytes);        /* dev2host(), cuda_ptr.cuh:62-69        */

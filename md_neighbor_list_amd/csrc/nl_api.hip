@@ -613,12 +613,15 @@ int nl_profile_stages(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_
 /* ------------------------------------------------------------------ buffers */
 
 int nl_buf_alloc(void** dev, void** host, size_t bytes) {
-  if (!dev || !host) return NL_ERR_ARG;
-  *dev = *host = nullptr;
-  if (hipMalloc(dev, bytes ? bytes : 16) != hipSuccess) return NL_ERR_NOMEM;
-  if (hipHostMalloc(host, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
-    (void)hipFree(*dev);
-    *dev = nullptr;
+  if (!dev && !host) return NL_ERR_ARG;
+  if (dev) *dev = nullptr;
+  if (host) *host = nullptr;
+  if (dev && hipMalloc(dev, bytes ? bytes : 16) != hipSuccess) return NL_ERR_NOMEM;
+  if (host && hipHostMalloc(host, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+    if (dev) {
+      (void)hipFree(*dev);
+      *dev = nullptr;
+    }
     return NL_ERR_NOMEM;
   }
   return NL_OK;
