@@ -83,8 +83,8 @@ def _cpu_model():
     return "unknown"
 
 
-def _traffic_from_profiles():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc.json), or None."""
+def _traffic_from_profiles(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC passes (profiles/*_pmc.json), or None."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
@@ -94,7 +94,8 @@ def _traffic_from_profiles():
     if not best:
         return None
     try:
-        return json.load(open(best)).get("fill_kernel_hbm_bytes_per_launch")
+        d = json.load(open(best))
+        return d.get("hbm_bytes_per_launch", {}).get(kernel)
     except Exception:
         return None
 
@@ -124,10 +125,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal on a one-GPU box (NL_BENCH_REHEARSAL=1): all ranks share GPU 0 and talk over gloo (host staging);
+    # exercises every line of the N > 1 path except RCCL itself.  Never used by the driver's runs.
+    rehearsal = os.environ.get("NL_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    red_dev = "cpu" if rehearsal else dev  # device of the two scalar reductions at the end
 
     density = 0.5 if args.workload == "cfg3" else 1.0
     if args.workload == "cfg4":
@@ -170,8 +180,8 @@ def main():
     nl.synchronize()
 
     npairs_local = nl.half_number_of_pairs()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    p = torch.tensor([npairs_local], dtype=torch.int64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    p = torch.tensor([npairs_local], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(p, op=dist.ReduceOp.SUM)
@@ -188,13 +198,25 @@ def main():
         n_loc, p_loc = (n_total if world == 1 else st.n_total), npairs_local
         roofline = None
         if stages:
-            # algorithmic bytes of one FILL launch: read sorted positions (16|32 B) + sorted_row (4 B) +
-            # key_pointer (4 B) per particle, write 4 B per half pair
-            b_fill = n_loc * (vec_bytes + 8) + 4 * p_loc
-            gbs = b_fill / (stages["fill"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_sweep<FILL>", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": _traffic_from_profiles(),
-                        "algorithmic_bytes_per_launch": b_fill, "kernel_ms": round(stages["fill"], 4),
+            # Dominant kernel = the pair search.  With hit masks (default) it is the COUNT_MASKS sweep, which runs
+            # every distance test once and decides every list entry; the expansion kernel only places them.  It is
+            # charged the algorithmic bytes of the search + append step: sorted positions
+            # (16|32 B) + sorted_row (4 B) read, counts (4 B) and the list (4 B per half pair) written.
+            info = nl.build_info()
+            if info["masks"]:
+                kname, kms = ("k_sweep_count_masks_f32" if args.dtype == "f32" else "k_sweep<double,COUNT_MASKS>"), stages["count"]
+            elif stages["fill"] >= stages["count"]:
+                kname, kms = "k_sweep<FILL>", stages["fill"]
+            else:
+                kname, kms = "k_sweep<COUNT>", stages["count"]
+            b_search = n_loc * (vec_bytes + 8) + 4 * p_loc
+            gbs = b_search / (kms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": _traffic_from_profiles(kname) if world == 1 else None,
+                        "algorithmic_bytes_per_launch": b_search, "kernel_ms": round(kms, 4),
+                        "note": "VALU-issue bound, not HBM bound: 10 VALU + 3 SALU per 64 distance tests (DESIGN.md "
+                                "section 4); `build` gives the whole-build HBM fraction",
                         "stages_ms": {k: round(v, 4) for k, v in stages.items()}}
         b_build = n_total * vec_bytes + 4 * npairs + 4 * (n_total + 1) + 4 * n_total
         build_gbs = b_build / (ms_per_step * 1e-3) / 1e9
@@ -211,6 +233,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
+            **({"rehearsal": "ranks share one GPU over gloo: not a measurement"} if rehearsal else {}),
             "config": {"workload": f"uniform random box, N={n_total}, rho={density}, rc={RC}, "
                                    f"{'fp32 float4' if args.dtype == 'f32' else 'fp64 double4'} positions, half list "
                                    f"(CSR in original particle order), mesh {mesh[0]}x{mesh[1]}x{mesh[2]}",

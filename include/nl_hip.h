@@ -90,9 +90,12 @@ int nl_make_list(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_t n, 
 /* Slab (domain-decomposed) build, SURVEY.md section 8e -- no reference counterpart (the reference is single GPU).
  * The handle describes the GLOBAL box.  This rank owns the cell layers z in [z_lo, z_hi) of the global mesh and
  * passes n_rows owned particles first, then n - n_rows ghost particles lying in the two periodic neighbour layers
- * (z_lo-1 and z_hi, modulo mesh_z).  gid_dev: global particle ids (NULL = identity).  Rows are built for the
+ * (z_lo-1 and z_hi, modulo mesh_z).  gid_dev: global particle ids (NULL = identity; NL_GID_IN_W = the id is stored
+ * in the w component of each position, as the bit pattern of an int32 (F32) / int64 (F64), which halves the
+ * number of halo messages).  Rows are built for the
  * owned particles only: row r holds the global ids j > gid[r] within the cut-off, so that the union over ranks
  * is exactly the global half list.  z_lo = 0, z_hi = mesh_z, n_rows = n is the single-GPU build. */
+#define NL_GID_IN_W ((const int32_t*)1)
 int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
                       int32_t n, int32_t z_lo, int32_t z_hi, void* stream, int sync);
 
@@ -132,6 +135,10 @@ int nl_get_sorted(nl_handle_t h, const int32_t** cell_start_dev, const void** so
 /* Diagnostic cycle accumulators of the kernels (filled only when NL_DEBUG_FLAGS & 4 is set in the environment). */
 int nl_debug_read(nl_handle_t h, uint64_t* out, int32_t n, int reset);
 int nl_debug_occupancy(int32_t out[8]); /* LDS per CU/block (KiB), occupancy API answers, LDS bytes, registers */
+/* How the last build was organised: info[0] = 1 when the COUNT sweep kept hit masks and the list was expanded from
+ * them (0: two distance sweeps), info[1] = configured sweep variant, info[2] = LDS batch capacity (particles),
+ * info[3] = compute units of the device. */
+int nl_get_build_info(nl_handle_t h, int32_t info[4]);
 int nl_last_error(nl_handle_t h);     /* status of the last failed call on this handle */
 int nl_last_hip_error(nl_handle_t h); /* raw hipError_t behind the last NL_ERR_HIP */
 

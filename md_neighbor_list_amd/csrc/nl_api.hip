@@ -45,8 +45,10 @@ struct nl_handle_s {
   int32_t* count = nullptr;
   int32_t* key_pointer = nullptr;
   int32_t* progress = nullptr;
-  int32_t* base_sorted = nullptr;  // key_pointer of every sorted slot (persistent sweep)
-  int sweep_variant = 1;           // 1: one workgroup per cell (k_sweep); 2: persistent + LDS-DMA (k_sweep_p, fp32)
+  int32_t* base_sorted = nullptr;  // key_pointer of every sorted slot (persistent sweep, mask expansion)
+  uint32_t* masks = nullptr;       // [n][64] hit bits of every sorted slot, between COUNT_MASKS and k_fill_masks
+  int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps; 2: persistent LDS-DMA sweeps (fp32);
+                                   // 3: COUNT keeping hit masks + mask expansion (default)
   int num_cus = 256;
   unsigned long long* dbg_buf = nullptr;
   int dbg_flags = 0, dbg_wg_per_cu = 4;  // diagnostics (NL_DEBUG_FLAGS, NL_DEBUG_WG_PER_CU)
@@ -76,6 +78,7 @@ struct nl_handle_s {
   int last_error = NL_OK, last_hip = 0;
   // arguments of the last build (to re-run the fill after growing the list)
   int32_t b_mzl = 0, b_slab = 0, b_zlo = 0, b_stride = 4;
+  bool b_use_masks = false;  // this build: COUNT keeps hit masks and the list is expanded from them
   const void* b_q = nullptr;
   const int32_t* b_gid = nullptr;
 };
@@ -174,6 +177,7 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.total = h->totals + 1;
   a.capacity = h->capacity;
   a.status = h->status;
+  a.masks = h->masks;
   a.dbg = h->dbg_flags;
   a.dbg_buf = h->dbg_buf;
   return a;
@@ -201,6 +205,21 @@ template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) 
       return;
     }
   }
+  if (h->b_use_masks) {
+    if (mode == MODE_COUNT) {
+      if constexpr (sizeof(T) == 4)
+        hipLaunchKernelGGL(k_sweep_count_masks_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+      else
+        hipLaunchKernelGGL((k_sweep<T, MODE_COUNT_MASKS>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+    } else {
+      const int32_t nbp = (h->n + 255) / 256;
+      if (h->n > 0)
+        hipLaunchKernelGGL(k_row_base, dim3(nbp), dim3(256), 0, s, h->key_pointer, h->sorted_row, h->n_rows, h->n,
+                           h->base_sorted);
+      hipLaunchKernelGGL((k_fill_masks<T>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a, h->base_sorted);
+    }
+    return;
+  }
   if (mode == MODE_COUNT) {
     if constexpr (sizeof(T) == 4)
       hipLaunchKernelGGL(k_sweep_count_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
@@ -218,12 +237,15 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   const int64_t ncl = (int64_t)h->m[0] * h->m[1] * mzl;
   h->ncell_local = ncl;
   h->b_mzl = mzl, h->b_slab = slab, h->b_zlo = z_lo, h->b_stride = stride, h->b_q = q_dev, h->b_gid = gid;
+  // Hit masks pay off while a cell's stencil fits one LDS batch; where the mean stencil (27 cells) is close to or
+  // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
+  h->b_use_masks = h->sweep_variant == 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
   const int32_t nbp = (n + 255) / 256;
   const T* q = static_cast<const T*>(q_dev);
 
   // cell histogram and the status word are one allocation: one memset node
   // ... followed by the 16 cell tickets of the two persistent sweeps
-  HIPCHK(h, hipMemsetAsync(h->cell_count, 0, sizeof(int32_t) * (size_t)(h->ncell + 1 + 16), s));
+  HIPCHK(h, hipMemsetAsync(h->cell_count, 0, sizeof(int32_t) * (size_t)(h->ncell + 1 + 16 + 1), s));
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
   if (n > 0) hipLaunchKernelGGL((k_hash<T>), dim3(nbp), dim3(256), 0, s, q, stride, n, g, h->cell_count, h->rank, h->status);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_CELL_SCAN], s));
@@ -369,7 +391,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
-    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) == 2 ? 2 : 1;
+    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(3, std::max(1, atoi(v)));
     if (const char* v = getenv("NL_DEBUG_FLAGS")) h->dbg_flags = atoi(v);
     if (const char* v = getenv("NL_DEBUG_WG_PER_CU")) h->dbg_wg_per_cu = std::max(1, atoi(v));
   }
@@ -381,7 +403,7 @@ int nl_destroy(nl_handle_t h) {
   if (!h) return NL_ERR_ARG;
   (void)hipSetDevice(h->device);
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
-  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->count, h->key_pointer, h->progress, h->base_sorted, h->dbg_buf, h->cell_count,
+  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->count, h->key_pointer, h->progress, h->base_sorted, h->masks, h->dbg_buf, h->cell_count,
                   h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -411,6 +433,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   if ((rc = dev_alloc(h, &h->key_pointer, 4 * (n + 32)))) return rc;
   if ((rc = dev_alloc(h, &h->progress, 4 * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->base_sorted, 4 * (n + 16)))) return rc;
+  if (h->sweep_variant == 3 && (rc = dev_alloc(h, &h->masks, 4 * (size_t)WAVE * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->dbg_buf, 8 * (64 + 4 * 4096)))) return rc;
   HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
   if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64)))) return rc;
@@ -457,6 +480,7 @@ int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const 
   if (h->n_max <= 0 && n > 0) return fail(h, NL_ERR_STATE);
   if (n < 0 || n_rows < 0 || n_rows > n || n > h->n_max || (q_stride != 3 && q_stride != 4) || (!q_dev && n > 0))
     return fail(h, NL_ERR_ARG);
+  if (gid_dev == NL_GID_IN_W && q_stride != 4) return fail(h, NL_ERR_ARG);
   const int32_t mz = h->m[2];
   if (z_lo < 0 || z_hi > mz || z_lo >= z_hi) return fail(h, NL_ERR_ARG);
   const int32_t owned = z_hi - z_lo;
@@ -567,6 +591,15 @@ int nl_debug_occupancy(int32_t out[8]) {
   (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_sweep_p<float, MODE_COUNT>));
   out[6] = (int32_t)fa.sharedSizeBytes;
   out[7] = fa.numRegs;
+  return NL_OK;
+}
+
+int nl_get_build_info(nl_handle_t h, int32_t info[4]) {
+  if (!h || !info) return NL_ERR_ARG;
+  info[0] = h->b_use_masks ? 1 : 0;
+  info[1] = h->sweep_variant;
+  info[2] = h->dtype == NL_F32 ? SweepCfg<float>::CAP : SweepCfg<double>::CAP;
+  info[3] = h->num_cus;
   return NL_OK;
 }
 

@@ -136,7 +136,12 @@ __global__ void __launch_bounds__(256) k_reorder(const T* __restrict__ q, int32_
   const int32_t dst = cell_start[c] + r;
   Pos<T> p;
   p.x = x, p.y = y, p.z = z;
-  p.gid = gid ? gid[i] : i;
+  if (gid == reinterpret_cast<const int32_t*>(1)) {  // NL_GID_IN_W: the id travels in the w component of the Vec
+    if constexpr (sizeof(T) == 4) p.gid = __float_as_int(q[(size_t)i * 4 + 3]);
+    else p.gid = (int32_t)__double_as_longlong(q[(size_t)i * 4 + 3]);
+  } else {
+    p.gid = gid ? gid[i] : i;
+  }
   if constexpr (sizeof(T) == 8) p.row = i;
   sorted[dst] = p;
   sorted_row[dst] = i;
@@ -294,7 +299,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
 //          CSR row (no staging row + transpose as in kernel_impl.cuh:218-239).
 // Half-list rule: the pair is kept in the row of the smaller id (RegistInteractPair neighlist_cpu.hpp:225-236),
 // so lane j is accepted only if gid_j > gid_i; that also drops j == i.
-enum { MODE_COUNT = 0, MODE_FILL = 1 };
+enum { MODE_COUNT = 0, MODE_FILL = 1, MODE_COUNT_MASKS = 2 };  // COUNT_MASKS: COUNT that also keeps every hit mask
 
 // n / d for 0 <= n < 2^31 and a divisor fixed at launch: q = (umulhi(n, m) + n) >> s  (Granlund-Montgomery
 // round-up form), evaluated without the 33-bit overflow.  The host fills m and s (fastdiv_make in nl_api.hip).
@@ -321,13 +326,14 @@ template <typename T> struct SweepArgs {
   const int64_t* __restrict__ total;
   int64_t capacity;
   uint32_t* __restrict__ status;
+  uint32_t* __restrict__ masks;  // [n][64]: bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
   int32_t dbg;  // diagnostics only (NL_DEBUG_FLAGS): 1 = skip the search, 2 = skip the staging copy; 0 in production
 };
 
 template <typename T> struct SweepCfg;
 template <> struct SweepCfg<float> { static constexpr int CAP = 1280; };   // 20 KB of LDS: 8 workgroups = 32 waves per CU
-template <> struct SweepCfg<double> { static constexpr int CAP = 1024; };  // 32 KB of LDS
+template <> struct SweepCfg<double> { static constexpr int CAP = 1280; };  // 40 KB of LDS (registers, not LDS, limit fp64 occupancy)
 
 constexpr int SWEEP_WAVES = 4;
 constexpr int SWEEP_G = 6;
@@ -336,12 +342,21 @@ constexpr int NSEG = 18;
 // One group of GC (compile-time, 1..6) i-particles against the nj staged j-particles.
 // pi_l / base_l: lane k < GC holds i-particle k and the list offset of its row.  Returns, in lane k, the number
 // of accepted partners of i-particle k.  All per-i state is wave-uniform (SGPRs): position, id, running count.
+// COUNT_MASKS additionally keeps every hit: one VGPR per i-particle in which lane l sets bit t when staged
+// particle t*64 + l is accepted (2 VALU per test, no scalar work); the 64 words of an i-particle go to
+// a.masks[(slot0 + k) * 64 + l] at the end (store_masks: only for cells whose stencil fits one LDS batch, which
+// also bounds t by CAP/64 <= 32).
 template <typename T, int MODE, int GC>
 __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos<T>* tile, int32_t nj,
-                                                int32_t ntiles, int lane, const Pos<T>& pi_l, int32_t base_l) {
+                                                int32_t ntiles, int lane, const Pos<T>& pi_l, int32_t base_l,
+                                                int32_t slot0 = 0, bool store_masks = false) {
+  static_assert(SweepCfg<T>::CAP / WAVE <= 32, "one bit per j-tile in a 32-bit word");
   T xi[GC], yi[GC], zi[GC];
   int32_t gi[GC];
   uint32_t cur[GC];  // COUNT: hits so far; FILL: list offset of the row + hits so far
+  uint32_t bits[GC];  // COUNT_MASKS: bit t of lane l = staged particle t*64 + l accepted
+#pragma unroll
+  for (int k = 0; k < GC; k++) bits[k] = 0;
 #pragma unroll
   for (int k = 0; k < GC; k++) {
     if constexpr (sizeof(T) == 4) {
@@ -360,7 +375,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   // One tile of 64 staged j-particles (lanes) against the GC i-particles (SGPRs).  All vector work of the GC
   // tests comes first (masks land in SGPR pairs), the scalar bookkeeping afterwards: a scalar instruction that
   // consumes a v_cmp result stalls the wave until the compare has left the VALU.
-  auto test_tile = [&](const Pos<T>& pj) {
+  auto test_tile = [&](const Pos<T>& pj, int32_t tix) {
     uint64_t mask[GC];
     bool hit[GC];  // per-lane predicate: lives in an SGPR pair as a lane mask, costs no VALU
 #pragma unroll
@@ -383,6 +398,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
           *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + boff) = pj.gid;
         }
       }
+      if (MODE == MODE_COUNT_MASKS) bits[k] = hit[k] ? (bits[k] | (1u << tix)) : bits[k];
       cur[k] += (uint32_t)__popcll(mask[k]);
     }
   };
@@ -395,33 +411,31 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   int32_t t = 0;
   for (; t + 1 < ntiles; t += 2) {  // both tests unconditional, so neither load can be sunk next to its use
     pb = tile[(t + 1) * WAVE + lane];
-    test_tile(pa);
+    test_tile(pa, t);
     pa = tile[min((t + 2) * WAVE + lane, last)];
-    test_tile(pb);
+    test_tile(pb, t + 1);
   }
-  if (t < ntiles) test_tile(pa);
+  if (t < ntiles) test_tile(pa, t);
+  if (MODE == MODE_COUNT_MASKS) {
+    if (store_masks) {
+#pragma unroll
+      for (int k = 0; k < GC; k++) a.masks[(size_t)(slot0 + k) * WAVE + lane] = bits[k];
+    }
+  }
   uint32_t mine = 0;
 #pragma unroll
   for (int k = 0; k < GC; k++) mine = lane == k ? cur[k] : mine;
   return (int32_t)(MODE == MODE_FILL ? mine - (uint32_t)base_l : mine);
 }
 
-template <typename T, int MODE>
-__device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
-  constexpr int CAP = SweepCfg<T>::CAP;
-  constexpr int G = SWEEP_G;
-  static_assert(G == 6, "search_group dispatch covers group sizes 1..6");
-  __shared__ Pos<T> tile[CAP];
+// Everything a workgroup knows about its i-cell: the cell's own particles [ibeg, ibeg + ni) and, per lane
+// s < NSEG, segment s of the stencil stream (start in the sorted array, length, offset in the stream).
+struct CellCtx {
+  int32_t ibeg, ni, seg_src, seg_len, seg_off, total_j;
+};
 
-  if (MODE == MODE_FILL) {
-    if (a.total[0] > a.capacity) {  // uniform: every workgroup leaves, nothing is written out of bounds
-      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
-      return;
-    }
-  }
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
+// Maps the workgroup to its i-cell (XCD-aware) and loads the segment table.  Returns false for an empty cell.
+template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs<T>& a, int lane, CellCtx& c) {
   // XCD-aware cell order: blocks b, b+8, b+16.. share an XCD (and its L2), so give each XCD a contiguous
   // range of cells (a z-slab of the box) instead of every 8th cell.
   int32_t w;
@@ -431,12 +445,13 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   }
   const int32_t wy = (int32_t)fastdiv((uint32_t)w, a.div_mx), cx = w - wy * a.mx;
   const int32_t wz = (int32_t)fastdiv((uint32_t)wy, a.div_my), cy = wy - wz * a.my, cz = wz + (a.slab ? 1 : 0);
-  const int32_t c = cx + (cy + cz * a.my) * a.mx;
-  const int32_t ibeg = a.cell_start[c], ni = a.cell_start[c + 1] - ibeg;
+  const int32_t cell = cx + (cy + cz * a.my) * a.mx;
+  c.ibeg = a.cell_start[cell];
+  c.ni = a.cell_start[cell + 1] - c.ibeg;
 
   // (the empty-cell exit comes after the segment-table loads so that both round trips are in flight together)
   // Segment table, one segment per lane (lanes >= 18 hold empty segments): 9 (dz,dy) rows x 2 x-parts.
-  int32_t seg_src = 0, seg_len = 0;
+  c.seg_src = 0, c.seg_len = 0;
   if (lane < NSEG) {
     // slots 0..8 = first x-part of the nine (dz,dy) rows (never empty in the interior), 9..17 = the wrapped part
     const int32_t s = lane % 9, part = lane / 9, dz = s / 3 - 1, dy = s % 3 - 1;
@@ -456,12 +471,22 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
       x0 = cx - 1, x1 = part ? cx - 1 : cx + 2;
     }
     const int32_t rowbase = (y + z * a.my) * a.mx;
-    seg_src = a.cell_start[rowbase + x0];
-    seg_len = a.cell_start[rowbase + x1] - seg_src;
+    c.seg_src = a.cell_start[rowbase + x0];
+    c.seg_len = a.cell_start[rowbase + x1] - c.seg_src;
   }
-  if (ni == 0) return;
-  const int32_t seg_off = scan32_dpp(seg_len) - seg_len;  // exclusive offsets in the staged stream
-  const int32_t total_j = __builtin_amdgcn_readlane(seg_off + seg_len, NSEG - 1);
+  if (c.ni == 0) return false;
+  c.seg_off = scan32_dpp(c.seg_len) - c.seg_len;  // exclusive offsets in the staged stream
+  c.total_j = __builtin_amdgcn_readlane(c.seg_off + c.seg_len, NSEG - 1);
+  return true;
+}
+
+// The pair search of one cell: stage the stencil stream into `tile` (in batches of CAP), search it group by group.
+template <typename T, int MODE, int CAP = SweepCfg<T>::CAP>
+__device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx& c, Pos<T>* tile, int tid, int lane,
+                                            int wave) {
+  constexpr int G = SWEEP_G;
+  static_assert(G == 6, "search_group dispatch covers group sizes 1..6");
+  const int32_t ibeg = c.ibeg, ni = c.ni, total_j = c.total_j;
   const int32_t nbatch = (total_j + CAP - 1) / CAP;
 
   // i-groups: `rounds` groups per wave, sized so that all waves get the same number of groups.
@@ -477,10 +502,10 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
     // to wave s mod 4: the nine never-empty slots spread 3/2/2/2); a wave copies a segment 128 particles at a
     // time with both 16-byte loads in flight before the LDS writes.
     for (int32_t sg = wave; sg < NSEG; sg += SWEEP_WAVES) {
-      const int32_t len = __builtin_amdgcn_readlane(seg_len, sg);
+      const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
       if (len == 0) continue;
-      const int32_t src = __builtin_amdgcn_readlane(seg_src, sg);
-      const int32_t off = __builtin_amdgcn_readlane(seg_off, sg) - win0;
+      const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
+      const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg) - win0;
       for (int32_t k = lane; k < len; k += 2 * WAVE) {
         const int32_t k1 = k + WAVE;
         const bool p1 = k1 < len;
@@ -517,14 +542,17 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
         if (MODE == MODE_FILL) base_l = a.key_pointer[row_l];
         if (batch) base_l += a.progress[row_l];  // entries already produced by earlier batches
       }
+      const int32_t slot0 = ibeg + i0;
+      // hit masks are kept only for single-batch cells (k_fill_masks re-searches the rest)
+      const bool keep = nbatch == 1 && CAP == SweepCfg<T>::CAP;
       int32_t mine;  // lane k < gcount: hits of i-particle k in this batch
       switch (gcount) {
-        case 1: mine = search_group<T, MODE, 1>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
-        case 2: mine = search_group<T, MODE, 2>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
-        case 3: mine = search_group<T, MODE, 3>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
-        case 4: mine = search_group<T, MODE, 4>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
-        case 5: mine = search_group<T, MODE, 5>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
-        default: mine = search_group<T, MODE, 6>(a, tile, nj, ntiles, lane, pi_l, base_l); break;
+        case 1: mine = search_group<T, MODE, 1>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        case 2: mine = search_group<T, MODE, 2>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        case 3: mine = search_group<T, MODE, 3>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        case 4: mine = search_group<T, MODE, 4>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        case 5: mine = search_group<T, MODE, 5>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        default: mine = search_group<T, MODE, 6>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
       }
       if (lane < gcount) {
         if (nbatch > 1) {
@@ -532,21 +560,151 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
           mine += before;
           a.progress[row_l] = mine;
         }
-        if (MODE == MODE_COUNT && batch == nbatch - 1) a.count[row_l] = mine;
+        if (MODE != MODE_FILL && batch == nbatch - 1) a.count[row_l] = mine;
       }
     }
   }
 }
 
+template <typename T, int MODE> __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
+  __shared__ Pos<T> tile[SweepCfg<T>::CAP];
+  if (MODE == MODE_FILL) {
+    if (a.total[0] > a.capacity) {  // uniform: every workgroup leaves, nothing is written out of bounds
+      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
+      return;
+    }
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  CellCtx c;
+  if (!cell_setup(a, lane, c)) return;
+  cell_search<T, MODE>(a, c, tile, tid, lane, wave);
+}
+
 template <typename T, int MODE> __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
   sweep_cell<T, MODE>(a);
 }
-// The fp32 COUNT pass is held to 80 SGPRs: the SGPR file admits 8 waves per SIMD only up to 80 per wave (6 at the
-// 102 the compiler takes by itself).  FILL needs the extra SGPRs (cursors + masks): capped, it spills into its
+// The fp32 COUNT passes are held to 80 SGPRs: the SGPR file admits 8 waves per SIMD only up to 80 per wave (6 at
+// the 102 the compiler takes by itself).  FILL needs the extra SGPRs (cursors + masks): capped, it spills into its
 // inner loop and loses more than the occupancy gains.
 __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_sweep_count_f32(SweepArgs<float> a) {
   sweep_cell<float, MODE_COUNT>(a);
+}
+__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep_count_masks_f32(SweepArgs<float> a) {  // (capped, it spills)
+  sweep_cell<float, MODE_COUNT_MASKS>(a);
+}
+
+// ------------------------------------------------------------------------------------------ list from masks
+// a8 + a9 without a second distance sweep: COUNT_MASKS left, for every i-particle (sorted slot), 64 words whose
+// bits say which particles of its cell's staged stencil stream were accepted.  This kernel re-stages only the ids
+// of the stream (4 B per particle) and expands the bits into the final CSR rows, one row per wave at a time:
+// lane l owns word l, a DPP prefix sum of the popcounts gives its offset inside the row, and it writes its set bits
+// one by one (bit t -> staged particle t*64 + l: LDS reads of one instruction always hit 64 different banks).
+// Cells whose stencil needed several LDS batches have no masks: they are searched again here, exactly as
+// k_sweep<FILL> does.
+__device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan over all 64 lanes
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
+k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
+  constexpr int CAP = SweepCfg<T>::CAP;
+  // 5 KiB: ids only, so 8 workgroups per CU keep enough loads in flight
+  __shared__ __attribute__((aligned(32))) int32_t gids[CAP];
+  if (a.total[0] > a.capacity) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  CellCtx c;
+  if (!cell_setup(a, lane, c)) return;
+  if (c.total_j > CAP) {
+    // No masks for this cell (its stencil needed several LDS batches in COUNT_MASKS): search it again, as
+    // k_sweep<FILL> does, in small batches through the id buffer.  Rare (very dense cells only).
+    constexpr int CAPS = (int)(CAP * sizeof(int32_t) / (sizeof(Pos<T>))) / WAVE * WAVE;
+    cell_search<T, MODE_FILL, CAPS>(a, c, reinterpret_cast<Pos<T>*>(gids), tid, lane, wave);
+    return;
+  }
+
+  // Rows of the cell are dealt to the waves in contiguous chunks.  A wave loads the masks and row offsets of up to
+  // RB rows first and only then starts storing: vmcnt retires in order, so a load issued behind stores would wait
+  // for the whole write latency of every store before it (that cost 1.7 us per row in the first version).
+  constexpr int RB = 16;
+  const int32_t per_wave = (c.ni + SWEEP_WAVES - 1) / SWEEP_WAVES;
+  const int32_t r_beg = min(wave * per_wave, c.ni), r_end = min(r_beg + per_wave, c.ni);
+  uint32_t w[RB];
+  int32_t base[RB];
+  auto load_rows = [&](int32_t r0) {
+#pragma unroll
+    for (int u = 0; u < RB; u++) {
+      const int32_t slot = c.ibeg + min(r0 + u, c.ni - 1);
+      w[u] = a.masks[(size_t)slot * WAVE + lane];
+      base[u] = base_sorted[slot];
+    }
+  };
+  load_rows(r_beg);  // issued before the id staging: independent of the segment table
+  if (a.dbg & 32) return;  // diagnostics: setup + loads only
+
+  // stage the ids of the stencil stream (the 4-byte id field of the 16/32-byte sorted particles)
+  for (int32_t sg = wave; sg < NSEG; sg += SWEEP_WAVES) {
+    const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
+    if (len == 0) continue;
+    const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
+    const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg);
+    for (int32_t k = lane; k < len; k += 2 * WAVE) {
+      const int32_t k1 = k + WAVE;
+      const bool p1 = k1 < len;
+      const int32_t v0 = a.sorted[src + k].gid;
+      const int32_t v1 = a.sorted[src + (p1 ? k1 : k)].gid;
+      gids[off + k] = v0;
+      if (p1) gids[off + k1] = v1;
+    }
+  }
+  __syncthreads();  // ids staged
+
+  const int32_t* const g = gids + lane;
+  for (int32_t r0 = r_beg; r0 < r_end; r0 += RB) {
+    if (r0 != r_beg) load_rows(r0);  // dense cells only
+    // four rows are expanded together: their LDS reads and stores are independent, so one trip through the
+    // bit loop pays the LDS latency once for four rows
+#pragma unroll
+    for (int u0 = 0; u0 < RB; u0 += 4) {
+      if (r0 + u0 >= r_end) continue;  // wave-uniform
+      uint32_t word[4], ptr[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        word[q] = r0 + u0 + q < r_end ? w[u0 + q] : 0u;
+        if (a.dbg & 16) word[q] = 0;  // diagnostics: no expansion
+        const int32_t cnt = __popc(word[q]);
+        ptr[q] = (uint32_t)(base[u0 + q] + scan64_dpp(cnt) - cnt);
+      }
+      while (word[0] | word[1] | word[2] | word[3]) {
+        int32_t val[4];
+        bool on[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          on[q] = word[q] != 0;
+          const int32_t t = on[q] ? __ffs(word[q]) - 1 : 0;
+          val[q] = g[t * WAVE];  // unconditional read of a valid slot: the four reads go out back to back
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (on[q]) {
+            *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + ((size_t)ptr[q] << 2)) = val[q];
+            ptr[q]++;
+            word[q] &= word[q] - 1;
+          }
+        }
+      }
+    }
+  }
 }
 
 }  // namespace nl

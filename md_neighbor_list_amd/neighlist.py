@@ -106,19 +106,29 @@ class NeighListGPU:
         self._n = self._n_rows = n
         check(self._lib.nl_make_list(self._h, q.data_ptr(), q.shape[1], n, stream, 1 if sync else 0), "nl_make_list")
 
+    GID_IN_W = "w"  # MakeNeighListSlab(gid=GID_IN_W): ids are stored in q[:, 3] as integer bit patterns (NL_GID_IN_W)
+
     def MakeNeighListSlab(self, q, gid, n_rows, z_lo, z_hi, sync=True):
         """Domain-decomposed build: rows for the first ``n_rows`` (owned) particles, the rest
-        are ghosts of the two neighbouring cell layers; ``gid`` are global ids (int32 device tensor or None)."""
+        are ghosts of the two neighbouring cell layers; ``gid`` are global ids: an int32 device tensor, None
+        (identity) or ``GID_IN_W`` (taken from the w component of the positions)."""
         n = self._check_q(q, None)
-        if gid is not None:
+        if isinstance(gid, str):
+            if gid != self.GID_IN_W or q.shape[1] != 4:
+                raise TypeError("gid='w' needs 4-component positions")
+            gid_ptr = 1
+        elif gid is not None:
             if gid.device.type != "cuda" or gid.dtype != torch.int32 or gid.numel() != n or not gid.is_contiguous():
                 raise TypeError("gid must be a contiguous int32 device tensor with one id per particle")
+            gid_ptr = gid.data_ptr()
+        else:
+            gid_ptr = None
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._q = (q, gid)
         self._n, self._n_rows = n, int(n_rows)
         check(
-            self._lib.nl_make_list_slab(self._h, q.data_ptr(), q.shape[1], gid.data_ptr() if gid is not None else None,
-                                        int(n_rows), n, int(z_lo), int(z_hi), stream, 1 if sync else 0),
+            self._lib.nl_make_list_slab(self._h, q.data_ptr(), q.shape[1], gid_ptr, int(n_rows), n, int(z_lo), int(z_hi),
+                                        stream, 1 if sync else 0),
             "nl_make_list_slab",
         )
 
@@ -188,6 +198,12 @@ class NeighListGPU:
         self._n = self._n_rows = n
         return dict(zip(_lib.STAGE_NAMES, (float(v) for v in ms)))
 
+
+    def build_info(self):
+        """{'masks': bool, 'variant': int, 'lds_batch': int, 'cus': int} of the last build."""
+        info = (C.c_int32 * 4)()
+        check(self._lib.nl_get_build_info(self._h, C.byref(info)), "nl_get_build_info")
+        return {"masks": bool(info[0]), "variant": int(info[1]), "lds_batch": int(info[2]), "cus": int(info[3])}
 
     def profile_last_build(self, reps=10):
         """Same for the last build (also a slab build); its position/id tensors are kept alive by this object."""

@@ -136,6 +136,12 @@ def setup(q_global: torch.Tensor, gid_global: torch.Tensor | None, box, rc, rank
     gid_all = torch.empty(n_rows + n_glo + n_ghi, dtype=torch.int32, device=q_global.device)
     q_all[:n_rows] = q_own
     gid_all[:n_rows] = gid_own
+    if q_all.shape[1] == 4:
+        # ids ride in the w component (bit pattern of an int32 / int64): one message per neighbour instead of two
+        if q_all.dtype == torch.float32:
+            q_all[:n_rows, 3].copy_(gid_own.view(torch.float32))
+        else:
+            q_all[:n_rows, 3].copy_(gid_own.to(torch.int64).view(torch.float64))
     return SlabState(rank, world, z_lo, z_hi, n_rows, q_all, gid_all, send_lo, send_hi, n_glo, n_ghi)
 
 
@@ -147,28 +153,29 @@ def exchange_ghosts(st: SlabState) -> None:
         return
     lo_peer, hi_peer = (st.rank - 1) % st.world, (st.rank + 1) % st.world
     n0, n1 = st.n_rows, st.n_rows + st.n_ghost_lo
+    in_w = st.q_all.shape[1] == 4  # ids travel inside the positions
     q_lo = st.q_all[:n0].index_select(0, st.send_lo_idx)
     q_hi = st.q_all[:n0].index_select(0, st.send_hi_idx)
-    g_lo = st.gid_all[:n0].index_select(0, st.send_lo_idx)
-    g_hi = st.gid_all[:n0].index_select(0, st.send_hi_idx)
-    # Order matters when lo_peer == hi_peer (world 2): the peer posts [send lo, send hi, recv lo-ghosts, recv
-    # hi-ghosts]; its "send hi" (its top layer) is my lower ghost layer and its "send lo" my upper ghost layer.
-    # So receive from hi_peer-as-sender-of-lo FIRST when the peers coincide.
-    if lo_peer == hi_peer:
-        spec = [("send", q_lo, lo_peer), ("send", g_lo, lo_peer), ("send", q_hi, hi_peer), ("send", g_hi, hi_peer),
-                ("recv", st.q_all[n1:n1 + st.n_ghost_hi], hi_peer), ("recv", st.gid_all[n1:n1 + st.n_ghost_hi], hi_peer),
-                ("recv", st.q_all[n0:n1], lo_peer), ("recv", st.gid_all[n0:n1], lo_peer)]
-    else:
-        spec = [("send", q_lo, lo_peer), ("send", g_lo, lo_peer), ("send", q_hi, hi_peer), ("send", g_hi, hi_peer),
-                ("recv", st.q_all[n0:n1], lo_peer), ("recv", st.gid_all[n0:n1], lo_peer),
-                ("recv", st.q_all[n1:n1 + st.n_ghost_hi], hi_peer), ("recv", st.gid_all[n1:n1 + st.n_ghost_hi], hi_peer)]
-    _p2p(spec, _staging())
+    sends = [("send", q_lo, lo_peer), ("send", q_hi, hi_peer)]
+    recv_lo = [("recv", st.q_all[n0:n1], lo_peer)]
+    recv_hi = [("recv", st.q_all[n1:n1 + st.n_ghost_hi], hi_peer)]
+    if not in_w:
+        g_lo = st.gid_all[:n0].index_select(0, st.send_lo_idx)
+        g_hi = st.gid_all[:n0].index_select(0, st.send_hi_idx)
+        sends = [("send", q_lo, lo_peer), ("send", g_lo, lo_peer), ("send", q_hi, hi_peer), ("send", g_hi, hi_peer)]
+        recv_lo.append(("recv", st.gid_all[n0:n1], lo_peer))
+        recv_hi.append(("recv", st.gid_all[n1:n1 + st.n_ghost_hi], hi_peer))
+    # Order matters when lo_peer == hi_peer (world 2): the peer posts [its bottom layer, its top layer]; its bottom
+    # layer is MY upper ghost layer and its top layer my lower one, so the upper-ghost receive is posted first.
+    recvs = recv_hi + recv_lo if lo_peer == hi_peer else recv_lo + recv_hi
+    _p2p(sends + recvs, _staging())
 
 
 def build(nl, st: SlabState, sync=True) -> None:
     """One domain-decomposed build on this rank: halo exchange, then the slab build on owned + ghost particles."""
     exchange_ghosts(st)
+    gid = nl.GID_IN_W if st.q_all.shape[1] == 4 else st.gid_all
     if st.world == 1:
-        nl.MakeNeighListSlab(st.q_all, st.gid_all, st.n_rows, 0, nl.mesh_size[2], sync=sync)
+        nl.MakeNeighListSlab(st.q_all, gid, st.n_rows, 0, nl.mesh_size[2], sync=sync)
     else:
-        nl.MakeNeighListSlab(st.q_all, st.gid_all, st.n_rows, st.z_lo, st.z_hi, sync=sync)
+        nl.MakeNeighListSlab(st.q_all, gid, st.n_rows, st.z_lo, st.z_hi, sync=sync)

@@ -36,7 +36,10 @@ def worker(rank, world, port, mode, case, ret):
         st = slab.setup(qt, None, box, rc)
         if mode == "oracle":
             slab.exchange_ghosts(st)
-            lq, gid = st.q_all.numpy(), st.gid_all.numpy()
+            lq = st.q_all.numpy()
+            # ids travel in the w component as integer bit patterns (slab.setup); ghosts have them only there
+            gid = (lq[:, 3].view(np.int32) if lq.dtype == np.float32 else lq[:, 3].view(np.int64).astype(np.int32)).copy()
+            assert np.array_equal(gid[: st.n_rows], st.gid_all.numpy()[: st.n_rows])
             # every ghost must lie in one of my two neighbour layers, every owned particle in my slab
             iz = slab.z_layer(st.q_all, box, rc).numpy()
             mz = int(box[2] / rc)
