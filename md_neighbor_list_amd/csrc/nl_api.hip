@@ -17,11 +17,16 @@ using namespace nl;
 
 namespace {
 
-struct HostResult {  // pinned; written by an async D2H copy at the end of every build
+// pinned; mirrors the int32 words [status, 16 tickets, pad, total_lo, total_hi] that follow the cell histogram on the
+// device; filled by ONE async D2H copy at the end of every build
+struct HostResult {
   uint32_t status;
-  uint32_t pad;
-  int64_t total;
+  uint32_t tickets[17];
+  uint32_t total_lo, total_hi;
+  int64_t total() const { return (int64_t)(((uint64_t)total_hi << 32) | total_lo); }
 };
+constexpr int META_TOTAL = 18;  // int32 offset of total_lo from the status word
+constexpr int META_WORDS = 20;
 
 }  // namespace
 
@@ -139,16 +144,23 @@ template <typename T> Grid<T> make_grid(nl_handle_t h, int32_t n_rows, int32_t z
 }
 
 // exclusive scan of in[n] into out[n+1]; grand total to total[0]
-int launch_scan(nl_handle_t h, const int32_t* in, int64_t n, int32_t* out, int64_t* total, hipStream_t s) {
+int launch_scan(nl_handle_t h, const int32_t* in, int64_t n, int32_t* out, int64_t* total, hipStream_t s,
+                uint32_t* total_split = nullptr) {
   if (n <= 0) {  // nothing to scan: out[0] = 0, total = 0 (a zero-size grid is not a valid launch)
     HIPCHK(h, hipMemsetAsync(out, 0, sizeof(int32_t), s));
     HIPCHK(h, hipMemsetAsync(total, 0, sizeof(int64_t), s));
+    if (total_split) HIPCHK(h, hipMemsetAsync(total_split, 0, 2 * sizeof(uint32_t), s));
+    return NL_OK;
+  }
+  if (n <= SCAN_SMALL_MAX) {  // one launch instead of three (totals of such short arrays fit int32)
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, in, (int32_t)n, total, out, total_split);
     return NL_OK;
   }
   const int32_t nb = (int32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum);
   hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, h->block_sum, nb, total);
-  hipLaunchKernelGGL(k_scan_down, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status);
+  hipLaunchKernelGGL(k_scan_down, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
+                     total_split);
   return NL_OK;
 }
 
@@ -216,7 +228,7 @@ template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) 
       if (h->n > 0)
         hipLaunchKernelGGL(k_row_base, dim3(nbp), dim3(256), 0, s, h->key_pointer, h->sorted_row, h->n_rows, h->n,
                            h->base_sorted);
-      hipLaunchKernelGGL((k_fill_masks<T>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a, h->base_sorted);
+      hipLaunchKernelGGL((k_fill_masks<T>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
     }
     return;
   }
@@ -258,7 +270,7 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   // (rows of particles rejected by the hash keep a stale count: such a build fails with its status anyway)
   launch_sweep<T>(h, MODE_COUNT, s);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_ROW_SCAN], s));
-  if (int rc = launch_scan(h, h->count, n_rows, h->key_pointer, h->totals + 1, s)) return rc;
+  if (int rc = launch_scan(h, h->count, n_rows, h->key_pointer, h->totals + 1, s, h->status + META_TOTAL)) return rc;
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_FILL], s));
   launch_sweep<T>(h, MODE_FILL, s);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_TOTAL], s));
@@ -267,8 +279,7 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
 }
 
 int enqueue_result_copy(nl_handle_t h, hipStream_t s) {
-  HIPCHK(h, hipMemcpyAsync(&h->host->status, h->status, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipMemcpyAsync(&h->host->total, h->totals + 1, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->host, h->status, sizeof(uint32_t) * META_WORDS, hipMemcpyDeviceToHost, s));
   return NL_OK;
 }
 
@@ -296,7 +307,7 @@ int finish(nl_handle_t h, bool may_grow) {
   h->pending = false;
   uint32_t st = h->host->status;
   if ((st & ST_CAPACITY) && !(st & ~ST_CAPACITY) && may_grow) {
-    int rc = grow_list(h, h->host->total);
+    int rc = grow_list(h, h->host->total());
     if (rc) return rc;
     HIPCHK(h, hipMemsetAsync(h->status, 0, sizeof(uint32_t), h->last_stream));
     if (h->dtype == NL_F32)
@@ -532,7 +543,7 @@ int nl_get_half_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_
   if (key_pointer_dev) *key_pointer_dev = h->key_pointer;
   if (sorted_list_dev) *sorted_list_dev = h->list;
   if (number_of_partners_dev) *number_of_partners_dev = h->count;
-  if (npairs) *npairs = h->host->total;
+  if (npairs) *npairs = h->host->total();
   return NL_OK;
 }
 
@@ -540,7 +551,7 @@ int nl_number_of_pairs(nl_handle_t h, int64_t* npairs) {
   if (!h || !npairs) return fail(h, NL_ERR_ARG);
   int rc = nl_synchronize(h);
   if (rc) return rc;
-  *npairs = h->host->total;
+  *npairs = h->host->total();
   return NL_OK;
 }
 

@@ -247,7 +247,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
                                                              const int64_t* __restrict__ block_off,
                                                              const int64_t* __restrict__ total,
                                                              int32_t* __restrict__ out,
-                                                             uint32_t* __restrict__ status) {
+                                                             uint32_t* __restrict__ status,
+                                                             uint32_t* __restrict__ total_split) {
   __shared__ int32_t wsum[SCAN_THREADS / WAVE];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_ITEMS;
@@ -284,6 +285,44 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
     const int64_t t = total[0];
     out[n] = (int32_t)t;
     if (t > 2147483647LL) atomicOr(status, ST_INDEX_OVERFLOW);
+    if (total_split) {  // the grand total next to the status word: one small device->host copy per build
+      total_split[0] = (uint32_t)t;
+      total_split[1] = (uint32_t)((unsigned long long)t >> 32);
+    }
+  }
+}
+
+// Same scan for short arrays in ONE launch (small boxes: a few thousand cells): a
+// single workgroup, every thread scans a contiguous run of K items, the 1024 run totals are scanned through LDS.
+constexpr int SCAN_SMALL_MAX = 4096;  // beyond that the per-thread runs get long and the three-kernel scan is faster
+__global__ void __launch_bounds__(1024) k_scan_small(const int32_t* __restrict__ in, int32_t n,
+                                                      int64_t* __restrict__ total, int32_t* __restrict__ out,
+                                                      uint32_t* __restrict__ total_split) {
+  __shared__ int32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t K = (n + 1023) / 1024;
+  const int32_t b = tid * K, e = min(b + K, n);
+  int32_t s = 0;
+  for (int32_t i = b; i < e; i++) s += in[i];
+  const int32_t inc = wave_incl_scan(s, lane);
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int32_t woff = 0, all = 0;
+  for (int k = 0; k < 16; k++) {
+    const int32_t v = wsum[k];
+    woff += k < w ? v : 0;
+    all += v;
+  }
+  int32_t run = woff + inc - s;
+  for (int32_t i = b; i < e; i++) {
+    const int32_t v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  if (tid == 0) {
+    out[n] = all;
+    total[0] = all;
+    if (total_split) total_split[0] = (uint32_t)all, total_split[1] = 0;
   }
 }
 
@@ -481,7 +520,7 @@ template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs
 }
 
 // The pair search of one cell: stage the stencil stream into `tile` (in batches of CAP), search it group by group.
-template <typename T, int MODE, int CAP = SweepCfg<T>::CAP>
+template <typename T, int MODE, int CAP = SweepCfg<T>::CAP, int NW = SWEEP_WAVES>
 __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx& c, Pos<T>* tile, int tid, int lane,
                                             int wave) {
   constexpr int G = SWEEP_G;
@@ -490,8 +529,8 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
   const int32_t nbatch = (total_j + CAP - 1) / CAP;
 
   // i-groups: `rounds` groups per wave, sized so that all waves get the same number of groups.
-  const int32_t rounds = (ni + SWEEP_WAVES * G - 1) / (SWEEP_WAVES * G);
-  const int32_t ngroups = rounds * SWEEP_WAVES;
+  const int32_t rounds = (ni + NW * G - 1) / (NW * G);
+  const int32_t ngroups = rounds * NW;
   const int32_t gsize = (ni + ngroups - 1) / ngroups;
 
   for (int32_t batch = 0; batch < nbatch; batch++) {
@@ -501,7 +540,7 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
     // ---- stage: copy the stream window [win0, win0 + nj) into LDS.  The waves share the segments (slot s goes
     // to wave s mod 4: the nine never-empty slots spread 3/2/2/2); a wave copies a segment 128 particles at a
     // time with both 16-byte loads in flight before the LDS writes.
-    for (int32_t sg = wave; sg < NSEG; sg += SWEEP_WAVES) {
+    for (int32_t sg = wave; sg < NSEG; sg += NW) {
       const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
       if (len == 0) continue;
       const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
@@ -528,7 +567,7 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
 
     // ---- search: this wave's groups against every tile of the batch
     const int32_t ntiles = (nj + WAVE - 1) / WAVE;
-    for (int32_t g = wave; g < ngroups; g += SWEEP_WAVES) {
+    for (int32_t g = wave; g < ngroups; g += NW) {
       const int32_t i0 = g * gsize;
       const int32_t gcount = min(gsize, ni - i0);  // wave-uniform; may be <= 0 for the last groups
       if (gcount <= 0) break;
@@ -612,11 +651,14 @@ __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan ov
   return v;
 }
 
+constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
+
 template <typename T>
-__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(EXPAND_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
-  // 5 KiB: ids only, so 8 workgroups per CU keep enough loads in flight
+  constexpr int EW = EXPAND_WAVES;
+  // 5 KiB: ids only, so many workgroups per CU keep enough loads in flight
   __shared__ __attribute__((aligned(32))) int32_t gids[CAP];
   if (a.total[0] > a.capacity) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
@@ -629,15 +671,15 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
     // No masks for this cell (its stencil needed several LDS batches in COUNT_MASKS): search it again, as
     // k_sweep<FILL> does, in small batches through the id buffer.  Rare (very dense cells only).
     constexpr int CAPS = (int)(CAP * sizeof(int32_t) / (sizeof(Pos<T>))) / WAVE * WAVE;
-    cell_search<T, MODE_FILL, CAPS>(a, c, reinterpret_cast<Pos<T>*>(gids), tid, lane, wave);
+    cell_search<T, MODE_FILL, CAPS, EW>(a, c, reinterpret_cast<Pos<T>*>(gids), tid, lane, wave);
     return;
   }
 
   // Rows of the cell are dealt to the waves in contiguous chunks.  A wave loads the masks and row offsets of up to
   // RB rows first and only then starts storing: vmcnt retires in order, so a load issued behind stores would wait
   // for the whole write latency of every store before it (that cost 1.7 us per row in the first version).
-  constexpr int RB = 16;
-  const int32_t per_wave = (c.ni + SWEEP_WAVES - 1) / SWEEP_WAVES;
+  constexpr int RB = 24;
+  const int32_t per_wave = (c.ni + EW - 1) / EW;
   const int32_t r_beg = min(wave * per_wave, c.ni), r_end = min(r_beg + per_wave, c.ni);
   uint32_t w[RB];
   int32_t base[RB];
@@ -646,14 +688,14 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
     for (int u = 0; u < RB; u++) {
       const int32_t slot = c.ibeg + min(r0 + u, c.ni - 1);
       w[u] = a.masks[(size_t)slot * WAVE + lane];
-      base[u] = base_sorted[slot];
+      base[u] = base_sorted[slot];  // (k_row_base: one gather kernel is cheaper than two dependent loads here)
     }
   };
   load_rows(r_beg);  // issued before the id staging: independent of the segment table
   if (a.dbg & 32) return;  // diagnostics: setup + loads only
 
   // stage the ids of the stencil stream (the 4-byte id field of the 16/32-byte sorted particles)
-  for (int32_t sg = wave; sg < NSEG; sg += SWEEP_WAVES) {
+  for (int32_t sg = wave; sg < NSEG; sg += EW) {
     const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
     if (len == 0) continue;
     const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
