@@ -50,6 +50,14 @@ struct nl_handle_s {
   int32_t* count = nullptr;
   int32_t* key_pointer = nullptr;
   int32_t* progress = nullptr;
+  // two-level binning (k_bin_*)
+  int32_t* row_count = nullptr;   // [nrows] zeroed per build, then row totals
+  int32_t* row_start = nullptr;   // [nrows + 1]
+  int32_t* blk_base = nullptr;    // [bin_blocks][nrows]
+  void* tmp_pos = nullptr;        // particles grouped by row
+  int32_t* tmp_row = nullptr;
+  int32_t bin_blocks = 0, bin_chunk = 0;
+  bool bin_two_level = true;      // NL_BINNING=1 selects the atomic-rank path (k_hash/k_reorder)
   int32_t* base_sorted = nullptr;  // key_pointer of every sorted slot (persistent sweep, mask expansion)
   uint32_t* masks = nullptr;       // [n][64] hit bits of every sorted slot, between COUNT_MASKS and k_fill_masks
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps; 2: persistent LDS-DMA sweeps (fp32);
@@ -255,17 +263,36 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   const int32_t nbp = (n + 255) / 256;
   const T* q = static_cast<const T*>(q_dev);
 
-  // cell histogram and the status word are one allocation: one memset node
-  // ... followed by the 16 cell tickets of the two persistent sweeps
-  HIPCHK(h, hipMemsetAsync(h->cell_count, 0, sizeof(int32_t) * (size_t)(h->ncell + 1 + 16 + 1), s));
-  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
-  if (n > 0) hipLaunchKernelGGL((k_hash<T>), dim3(nbp), dim3(256), 0, s, q, stride, n, g, h->cell_count, h->rank, h->status);
-  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_CELL_SCAN], s));
-  if (int rc = launch_scan(h, h->cell_count, ncl, h->cell_start, h->totals, s)) return rc;
-  if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_REORDER], s));
-  if (n > 0)
-    hipLaunchKernelGGL((k_reorder<T>), dim3(nbp), dim3(256), 0, s, q, stride, gid, n, g, h->cell_start, h->rank,
-                       static_cast<Pos<T>*>(h->sorted), h->sorted_row);
+  const int32_t nrows = h->m[1] * mzl;
+  const bool two_level = h->bin_two_level && nrows <= BIN_MAX_ROWS && h->m[0] <= BIN_MAX_MX;
+  // One allocation = [cell histogram | status, tickets, total (32 words) | row totals]: one memset node clears
+  // what this build's path needs (histogram + meta, or meta + row totals).
+  if (two_level) {
+    HIPCHK(h, hipMemsetAsync(h->cell_count + h->ncell, 0, sizeof(int32_t) * (size_t)(32 + nrows), s));
+    if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
+    if (n > 0)
+      hipLaunchKernelGGL((k_bin_rows<T>), dim3(h->bin_blocks), dim3(BIN_THREADS), 0, s, q, stride, n, h->bin_chunk, g, nrows,
+                         h->row_count, h->blk_base, h->status);
+    if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_CELL_SCAN], s));
+    if (int rc = launch_scan(h, h->row_count, nrows, h->row_start, h->totals, s)) return rc;
+    if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_REORDER], s));
+    if (n > 0)
+      hipLaunchKernelGGL((k_bin_scatter<T>), dim3(h->bin_blocks), dim3(BIN_THREADS), 0, s, q, stride, gid, n, h->bin_chunk, g,
+                         nrows, h->row_start, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row);
+    hipLaunchKernelGGL((k_bin_cells<T>), dim3(nrows), dim3(256), 0, s, g, nrows, h->row_start,
+                       static_cast<const Pos<T>*>(h->tmp_pos), h->tmp_row, h->cell_start, static_cast<Pos<T>*>(h->sorted),
+                       h->sorted_row);
+  } else {
+    HIPCHK(h, hipMemsetAsync(h->cell_count, 0, sizeof(int32_t) * (size_t)(h->ncell + 32), s));
+    if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
+    if (n > 0) hipLaunchKernelGGL((k_hash<T>), dim3(nbp), dim3(256), 0, s, q, stride, n, g, h->cell_count, h->rank, h->status);
+    if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_CELL_SCAN], s));
+    if (int rc = launch_scan(h, h->cell_count, ncl, h->cell_start, h->totals, s)) return rc;
+    if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_REORDER], s));
+    if (n > 0)
+      hipLaunchKernelGGL((k_reorder<T>), dim3(nbp), dim3(256), 0, s, q, stride, gid, n, g, h->cell_start, h->rank,
+                         static_cast<Pos<T>*>(h->sorted), h->sorted_row);
+  }
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_COUNT], s));
   // (rows of particles rejected by the hash keep a stale count: such a build fails with its status anyway)
   launch_sweep<T>(h, MODE_COUNT, s);
@@ -403,6 +430,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(3, std::max(1, atoi(v)));
+    if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_DEBUG_FLAGS")) h->dbg_flags = atoi(v);
     if (const char* v = getenv("NL_DEBUG_WG_PER_CU")) h->dbg_wg_per_cu = std::max(1, atoi(v));
   }
@@ -414,7 +442,7 @@ int nl_destroy(nl_handle_t h) {
   if (!h) return NL_ERR_ARG;
   (void)hipSetDevice(h->device);
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
-  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->count, h->key_pointer, h->progress, h->base_sorted, h->masks, h->dbg_buf, h->cell_count,
+  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->count, h->key_pointer, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->dbg_buf, h->cell_count,
                   h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -444,17 +472,30 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   if ((rc = dev_alloc(h, &h->key_pointer, 4 * (n + 32)))) return rc;
   if ((rc = dev_alloc(h, &h->progress, 4 * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->base_sorted, 4 * (n + 16)))) return rc;
+  {
+    const size_t nrows = (size_t)h->m[1] * h->m[2];
+    // chunk per block: 4096 particles, more for very large N so that blk_base stays small
+    h->bin_chunk = 4096;
+    while ((n + h->bin_chunk - 1) / h->bin_chunk > 1024) h->bin_chunk *= 2;
+    h->bin_blocks = (int32_t)((n + h->bin_chunk - 1) / h->bin_chunk);
+    if (h->bin_blocks < 1) h->bin_blocks = 1;
+    if ((rc = dev_alloc(h, &h->row_start, 4 * (nrows + 32)))) return rc;
+    if ((rc = dev_alloc(h, &h->blk_base, 4 * (nrows * (size_t)h->bin_blocks + 16)))) return rc;
+    if ((rc = dev_alloc(h, &h->tmp_pos, pos_bytes * (n + 16)))) return rc;
+    if ((rc = dev_alloc(h, &h->tmp_row, 4 * (n + 16)))) return rc;
+  }
   if (h->sweep_variant == 3 && (rc = dev_alloc(h, &h->masks, 4 * (size_t)WAVE * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->dbg_buf, 8 * (64 + 4 * 4096)))) return rc;
   HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
-  if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64)))) return rc;
+  if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64 + (size_t)h->m[1] * h->m[2])))) return rc;
+  h->row_count = h->cell_count + h->ncell + 32;
   if ((rc = dev_alloc(h, &h->cell_start, 4 * ((size_t)h->ncell + 32)))) return rc;
   const size_t nblk = std::max<size_t>(n, (size_t)h->ncell) / SCAN_BLOCK + 2;
   if ((rc = dev_alloc(h, &h->block_sum, 8 * nblk))) return rc;
   if ((rc = dev_alloc(h, &h->totals, 8 * 4))) return rc;
   h->status = reinterpret_cast<uint32_t*>(h->cell_count + h->ncell);  // cleared by the same memset as the histogram
   HIPCHK(h, hipMemset(h->totals, 0, 32));
-  HIPCHK(h, hipMemset(h->cell_count, 0, 4 * ((size_t)h->ncell + 64)));
+  HIPCHK(h, hipMemset(h->cell_count, 0, 4 * ((size_t)h->ncell + 64 + (size_t)h->m[1] * h->m[2])));
   h->n_max = n_max;
   if (!h->capacity_user) {
     // ideal-gas estimate of the half-pair count: N * rho * (2/3) pi rc^3, with 30 % head room

@@ -56,7 +56,8 @@ __device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(
 // idx.x + (idx.y + idx.z*my)*mx -- here with the z index taken relative to the local slab.
 // Returns -1 where the reference would index out of bounds, -2 for a particle outside this rank's layers.
 template <typename T>
-__device__ __forceinline__ int32_t local_cell(const Grid<T>& g, T x, T y, T z, int32_t* lz_out) {
+__device__ __forceinline__ int32_t local_cell(const Grid<T>& g, T x, T y, T z, int32_t* lz_out,
+                                              int32_t* row_out = nullptr) {
   const T t[3] = {mul_rn(x, g.ims[0]), mul_rn(y, g.ims[1]), mul_rn(z, g.ims[2])};
   int32_t idx[3];
   bool bad = false;
@@ -74,6 +75,7 @@ __device__ __forceinline__ int32_t local_cell(const Grid<T>& g, T x, T y, T z, i
   if (lz < 0) lz += g.m[2];
   if (lz >= g.mzl) return -2;
   *lz_out = lz;
+  if (row_out) *row_out = idx[1] + lz * g.m[1];  // the row of x-cells the particle lies in
   return idx[0] + (idx[1] + lz * g.m[1]) * g.m[0];
 }
 
@@ -326,6 +328,135 @@ __global__ void __launch_bounds__(1024) k_scan_small(const int32_t* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------- binning
+// a3 + a4 + a5 without one global atomic per particle (k_hash is bound by the ~20 G/s rate of scattered returning
+// atomics: 50 us per million particles).  Two-level counting sort through LDS:
+//   k_bin_rows     every block histograms its chunk of particles over the R = my*mzl ROWS of x-cells in LDS and
+//                  reserves its share of each row with one returning global atomic per (block, row);
+//   (scan)         exclusive scan of the R row totals -> row_start;
+//   k_bin_scatter  every block re-reads its chunk and appends {x,y,z,id} + input index to its rows' reserved
+//                  ranges (LDS cursors) in a temporary array: particles are now grouped by row;
+//   k_bin_cells    one workgroup per row: LDS histogram over the row's mx cells -> cell_start, then the row's
+//                  particles are placed in cell order into sorted[] / sorted_row[].
+// The cell of a particle is the reference's (local_cell above); x-cell and row are its two factors.
+constexpr int BIN_THREADS = 1024;
+constexpr int BIN_MAX_ROWS = 12288;  // 48 KiB of LDS counters
+constexpr int BIN_MAX_MX = 4096;
+
+template <typename T>
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_rows(const T* __restrict__ q, int32_t stride, int32_t n, int32_t chunk,
+                                                          Grid<T> g, int32_t nrows, int32_t* __restrict__ row_count,
+                                                          int32_t* __restrict__ blk_base, uint32_t* __restrict__ status) {
+  __shared__ int32_t hist[BIN_MAX_ROWS];
+  const int tid = threadIdx.x;
+  for (int32_t r = tid; r < nrows; r += BIN_THREADS) hist[r] = 0;
+  __syncthreads();
+  const int32_t beg = blockIdx.x * chunk, end = min(beg + chunk, n);
+  for (int32_t i = beg + tid; i < end; i += BIN_THREADS) {
+    T x, y, z;
+    load_xyz(q, stride, i, x, y, z);
+    int32_t lz = 0, row = 0;
+    const int32_t c = local_cell(g, x, y, z, &lz, &row);
+    if (c < 0) {
+      atomicOr(status, c == -1 ? ST_OUT_OF_BOX : ST_DOMAIN);
+      continue;
+    }
+    if (g.slab) {
+      const bool in_owned_layer = lz >= 1 && lz < g.mzl - 1;
+      if (in_owned_layer != (i < g.n_rows)) atomicOr(status, ST_DOMAIN);
+    }
+    atomicAdd(&hist[row], 1);
+  }
+  __syncthreads();
+  for (int32_t r = tid; r < nrows; r += BIN_THREADS) {
+    const int32_t h = hist[r];
+    blk_base[(size_t)blockIdx.x * nrows + r] = h ? atomicAdd(&row_count[r], h) : 0;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict__ q, int32_t stride,
+                                                             const int32_t* __restrict__ gid, int32_t n, int32_t chunk,
+                                                             Grid<T> g, int32_t nrows, const int32_t* __restrict__ row_start,
+                                                             const int32_t* __restrict__ blk_base, Pos<T>* __restrict__ tmp,
+                                                             int32_t* __restrict__ tmp_row) {
+  __shared__ int32_t cursor[BIN_MAX_ROWS];
+  const int tid = threadIdx.x;
+  for (int32_t r = tid; r < nrows; r += BIN_THREADS) cursor[r] = row_start[r] + blk_base[(size_t)blockIdx.x * nrows + r];
+  __syncthreads();
+  const int32_t beg = blockIdx.x * chunk, end = min(beg + chunk, n);
+  for (int32_t i = beg + tid; i < end; i += BIN_THREADS) {
+    T x, y, z;
+    load_xyz(q, stride, i, x, y, z);
+    int32_t lz = 0, row = 0;
+    const int32_t c = local_cell(g, x, y, z, &lz, &row);
+    if (c < 0) continue;
+    const int32_t dst = atomicAdd(&cursor[row], 1);
+    Pos<T> p;
+    p.x = x, p.y = y, p.z = z;
+    if (gid == reinterpret_cast<const int32_t*>(1)) {  // NL_GID_IN_W: the id travels in the w component of the Vec
+      if constexpr (sizeof(T) == 4) p.gid = __float_as_int(q[(size_t)i * 4 + 3]);
+      else p.gid = (int32_t)__double_as_longlong(q[(size_t)i * 4 + 3]);
+    } else {
+      p.gid = gid ? gid[i] : i;
+    }
+    if constexpr (sizeof(T) == 8) p.row = i;
+    tmp[dst] = p;
+    tmp_row[dst] = i;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, const int32_t* __restrict__ row_start,
+                                                   const Pos<T>* __restrict__ tmp, const int32_t* __restrict__ tmp_row,
+                                                   int32_t* __restrict__ cell_start, Pos<T>* __restrict__ sorted,
+                                                   int32_t* __restrict__ sorted_row) {
+  __shared__ int32_t cnt[BIN_MAX_MX];
+  __shared__ int32_t wsum[4];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t r = blockIdx.x, mx = g.m[0];
+  const int32_t beg = row_start[r], end = row_start[r + 1];
+  for (int32_t c = tid; c < mx; c += 256) cnt[c] = 0;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  // x-cell exactly as local_cell computes it (the particle passed the range checks in k_bin_rows)
+  auto xcell = [&](T x) {
+    int32_t v = (int32_t)mul_rn(x, g.ims[0]);
+    if (v < 0) v += mx;
+    if (v >= mx) v -= mx;
+    return v;
+  };
+  for (int32_t k = beg + tid; k < end; k += 256) atomicAdd(&cnt[xcell(tmp[k].x)], 1);
+  __syncthreads();
+  // exclusive scan of cnt[0..mx) in place, 256 entries at a time, and the row's slice of cell_start
+  for (int32_t base = 0; base < mx; base += 256) {
+    const int32_t c = base + tid;
+    const int32_t v = c < mx ? cnt[c] : 0;
+    const int32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int k = 0; k < w; k++) woff += wsum[k];
+    const int32_t carry = carry_s;
+    const int32_t excl = carry + woff + inc - v;
+    if (c < mx) {
+      cnt[c] = excl;
+      cell_start[(size_t)r * mx + c] = beg + excl;
+    }
+    __syncthreads();
+    if (tid == 255) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (r == nrows - 1 && tid == 0) cell_start[(size_t)nrows * mx] = end;
+  for (int32_t k = beg + tid; k < end; k += 256) {
+    const Pos<T> p = tmp[k];
+    const int32_t dst = beg + atomicAdd(&cnt[xcell(p.x)], 1);
+    sorted[dst] = p;
+    sorted_row[dst] = tmp_row[k];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- sweep
 // a7 + a8 + a9: the pair search.  One workgroup per i-cell.  The particles of the 27 neighbour cells
 // (9 contiguous x-runs of the cell-sorted array, periodic wrap as MakeNeighMeshId neighlist_gpu.hpp:125-142 /
@@ -375,10 +506,10 @@ template <> struct SweepCfg<float> { static constexpr int CAP = 1280; };   // 20
 template <> struct SweepCfg<double> { static constexpr int CAP = 1280; };  // 40 KB of LDS (registers, not LDS, limit fp64 occupancy)
 
 constexpr int SWEEP_WAVES = 4;
-constexpr int SWEEP_G = 6;
+constexpr int SWEEP_G = 5;
 constexpr int NSEG = 18;
 
-// One group of GC (compile-time, 1..6) i-particles against the nj staged j-particles.
+// One group of GC (compile-time, 1..5) i-particles against the nj staged j-particles.
 // pi_l / base_l: lane k < GC holds i-particle k and the list offset of its row.  Returns, in lane k, the number
 // of accepted partners of i-particle k.  All per-i state is wave-uniform (SGPRs): position, id, running count.
 // COUNT_MASKS additionally keeps every hit: one VGPR per i-particle in which lane l sets bit t when staged
@@ -524,7 +655,7 @@ template <typename T, int MODE, int CAP = SweepCfg<T>::CAP, int NW = SWEEP_WAVES
 __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx& c, Pos<T>* tile, int tid, int lane,
                                             int wave) {
   constexpr int G = SWEEP_G;
-  static_assert(G == 6, "search_group dispatch covers group sizes 1..6");
+  static_assert(G == 5, "search_group dispatch covers group sizes 1..5");
   const int32_t ibeg = c.ibeg, ni = c.ni, total_j = c.total_j;
   const int32_t nbatch = (total_j + CAP - 1) / CAP;
 
@@ -590,8 +721,7 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
         case 2: mine = search_group<T, MODE, 2>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
         case 3: mine = search_group<T, MODE, 3>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
         case 4: mine = search_group<T, MODE, 4>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        case 5: mine = search_group<T, MODE, 5>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        default: mine = search_group<T, MODE, 6>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        default: mine = search_group<T, MODE, 5>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
       }
       if (lane < gcount) {
         if (nbatch > 1) {
@@ -629,7 +759,8 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_s
 k_sweep_count_f32(SweepArgs<float> a) {
   sweep_cell<float, MODE_COUNT>(a);
 }
-__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep_count_masks_f32(SweepArgs<float> a) {  // (capped, it spills)
+__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
+k_sweep_count_masks_f32(SweepArgs<float> a) {
   sweep_cell<float, MODE_COUNT_MASKS>(a);
 }
 

@@ -266,8 +266,7 @@ k_sweep_p(SweepArgs<T> a, int32_t ncells_i, const int32_t* __restrict__ base_sor
             case 2: mine = search_group<T, MODE, 2>(a, cur, nj, ntiles, lane, pg, baseg); break;
             case 3: mine = search_group<T, MODE, 3>(a, cur, nj, ntiles, lane, pg, baseg); break;
             case 4: mine = search_group<T, MODE, 4>(a, cur, nj, ntiles, lane, pg, baseg); break;
-            case 5: mine = search_group<T, MODE, 5>(a, cur, nj, ntiles, lane, pg, baseg); break;
-            default: mine = search_group<T, MODE, 6>(a, cur, nj, ntiles, lane, pg, baseg); break;
+            default: mine = search_group<T, MODE, 5>(a, cur, nj, ntiles, lane, pg, baseg); break;
           }
           if (lane < gcount) {
             if (nbatch > 1) {
