@@ -18,7 +18,7 @@ all: lib inputs tools oracle
 lib: $(LIBDIR)/libnl_hip.so
 inputs: $(LIBDIR)/libnl_inputs.so
 
-$(LIBDIR)/libnl_hip.so: $(CSRC)/nl_api.hip $(CSRC)/nl_kernels.hpp $(CSRC)/nl_transpose.inc include/nl_hip.h
+$(LIBDIR)/libnl_hip.so: $(CSRC)/nl_api.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.inc) include/nl_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/nl_api.hip
 

@@ -136,7 +136,7 @@ int nl_get_sorted(nl_handle_t h, const int32_t** cell_start_dev, const void** so
 int nl_debug_read(nl_handle_t h, uint64_t* out, int32_t n, int reset);
 int nl_debug_occupancy(int32_t out[8]); /* LDS per CU/block (KiB), occupancy API answers, LDS bytes, registers */
 /* How the last build was organised: info[0] = 1 when the COUNT sweep kept hit masks and the list was expanded from
- * them (0: two distance sweeps), info[1] = configured sweep variant, info[2] = LDS batch capacity (particles),
+ * them, 2 when those masks came from the matrix-core search (0: two distance sweeps), info[1] = configured sweep variant, info[2] = LDS batch capacity (particles),
  * info[3] = compute units of the device. */
 int nl_get_build_info(nl_handle_t h, int32_t info[4]);
 int nl_last_error(nl_handle_t h);     /* status of the last failed call on this handle */

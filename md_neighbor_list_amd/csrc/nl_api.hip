@@ -38,6 +38,8 @@ struct nl_handle_s {
   float ims_f[3];
   double ims_d[3];
   float rc2_f = 0;
+  float ms_f[3];       // cell edge as the reference's float Vec holds it (neighlist_cpu.hpp:389-391)
+  float mfma_delta = 0;  // k_sweep_mfma_f32: half-width of the band that is re-tested exactly (mfma_delta())
 
   int32_t n_max = 0;
   int64_t capacity = 0;
@@ -61,7 +63,8 @@ struct nl_handle_s {
   int32_t* base_sorted = nullptr;  // key_pointer of every sorted slot (persistent sweep, mask expansion)
   uint32_t* masks = nullptr;       // [n][64] hit bits of every sorted slot, between COUNT_MASKS and k_fill_masks
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps; 2: persistent LDS-DMA sweeps (fp32);
-                                   // 3: COUNT keeping hit masks + mask expansion (default)
+                                   // 3 (default): VALU COUNT keeping hit masks + mask expansion;
+                                   // 4: as 3 with the fp32 COUNT on the matrix cores (k_sweep_mfma_f32; slower so far)
   int num_cus = 256;
   unsigned long long* dbg_buf = nullptr;
   int dbg_flags = 0, dbg_wg_per_cu = 4;  // diagnostics (NL_DEBUG_FLAGS, NL_DEBUG_WG_PER_CU)
@@ -92,6 +95,7 @@ struct nl_handle_s {
   // arguments of the last build (to re-run the fill after growing the list)
   int32_t b_mzl = 0, b_slab = 0, b_zlo = 0, b_stride = 4;
   bool b_use_masks = false;  // this build: COUNT keeps hit masks and the list is expanded from them
+  bool b_use_mfma = false;   // ... and the masks come from k_sweep_mfma_f32 (layout MASK_TILE16)
   const void* b_q = nullptr;
   const int32_t* b_gid = nullptr;
 };
@@ -198,6 +202,9 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.capacity = h->capacity;
   a.status = h->status;
   a.masks = h->masks;
+  for (int d = 0; d < 3; d++) a.ms[d] = sizeof(T) == 4 ? (T)h->ms_f[d] : (T)(h->L[d] / h->m[d]);
+  a.delta = (T)h->mfma_delta;
+  a.z_origin = h->b_slab ? h->b_zlo - 1 : 0;
   a.dbg = h->dbg_flags;
   a.dbg_buf = h->dbg_buf;
   return a;
@@ -227,16 +234,22 @@ template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) 
   }
   if (h->b_use_masks) {
     if (mode == MODE_COUNT) {
-      if constexpr (sizeof(T) == 4)
-        hipLaunchKernelGGL(k_sweep_count_masks_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
-      else
+      if constexpr (sizeof(T) == 4) {
+        if (h->b_use_mfma)
+          hipLaunchKernelGGL(k_sweep_mfma_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+        else
+          hipLaunchKernelGGL(k_sweep_count_masks_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+      } else
         hipLaunchKernelGGL((k_sweep<T, MODE_COUNT_MASKS>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
     } else {
       const int32_t nbp = (h->n + 255) / 256;
       if (h->n > 0)
         hipLaunchKernelGGL(k_row_base, dim3(nbp), dim3(256), 0, s, h->key_pointer, h->sorted_row, h->n_rows, h->n,
                            h->base_sorted);
-      hipLaunchKernelGGL((k_fill_masks<T>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
+      if (h->b_use_mfma)
+        hipLaunchKernelGGL((k_fill_masks<T, MASK_TILE16>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
+      else
+        hipLaunchKernelGGL((k_fill_masks<T, MASK_LANE64>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
     }
     return;
   }
@@ -259,7 +272,8 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   h->b_mzl = mzl, h->b_slab = slab, h->b_zlo = z_lo, h->b_stride = stride, h->b_q = q_dev, h->b_gid = gid;
   // Hit masks pay off while a cell's stencil fits one LDS batch; where the mean stencil (27 cells) is close to or
   // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
-  h->b_use_masks = h->sweep_variant == 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
+  h->b_use_masks = h->sweep_variant >= 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
+  h->b_use_mfma = h->b_use_masks && h->sweep_variant == 4 && sizeof(T) == 4;
   const int32_t nbp = (n + 255) / 256;
   const T* q = static_cast<const T*>(q_dev);
 
@@ -410,9 +424,22 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     h->L[d] = L[d], h->m[d] = m[d];
     // ms_ and ims_ live in a Vec of the position type (neighlist_cpu.hpp:12,389-391,409-411)
     const float ms_f = (float)(L[d] / m[d]);
+    h->ms_f[d] = ms_f;
     h->ims_f[d] = (float)(1.0 / (double)ms_f);
     const double ms_d = L[d] / m[d];
     h->ims_d[d] = 1.0 / ms_d;
+  }
+  {
+    // k_sweep_mfma_f32 decides a pair from acc = (|ui|^2 - rc2) + |uj|^2 - 2 ui.uj (local coordinates u, matrix
+    // core) only where |acc| >= delta.  For a pair within a factor 4 of the cut-off every term is bounded by
+    // S = (|ui| + |uj|)^2 <= (cell diagonal + rc)^2 (|ui| <= half the diagonal, |uj| <= |ui| + rc): about eight
+    // roundings of relative size 2^-24 on terms <= S, plus the rounding of the local coordinates and of the
+    // reference's own r2, stay below 2^-20.5 S; delta = 2^-18 S leaves a factor 5.  Farther pairs are decided by
+    // a margin of >= 0.15 S' against an error of 1e-6 S' (S' their own term bound).
+    double diag2 = 0;
+    for (int d = 0; d < 3; d++) diag2 += (double)h->ms_f[d] * h->ms_f[d];
+    const double S = (std::sqrt(diag2) + rc) * (std::sqrt(diag2) + rc);
+    h->mfma_delta = (float)(S / 262144.0);
   }
   h->ncell = (int64_t)m[0] * m[1] * m[2];
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -429,7 +456,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
-    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(3, std::max(1, atoi(v)));
+    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(4, std::max(1, atoi(v)));
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_DEBUG_FLAGS")) h->dbg_flags = atoi(v);
     if (const char* v = getenv("NL_DEBUG_WG_PER_CU")) h->dbg_wg_per_cu = std::max(1, atoi(v));
@@ -484,7 +511,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
     if ((rc = dev_alloc(h, &h->tmp_pos, pos_bytes * (n + 16)))) return rc;
     if ((rc = dev_alloc(h, &h->tmp_row, 4 * (n + 16)))) return rc;
   }
-  if (h->sweep_variant == 3 && (rc = dev_alloc(h, &h->masks, 4 * (size_t)WAVE * (n + 16)))) return rc;
+  if (h->sweep_variant >= 3 && (rc = dev_alloc(h, &h->masks, 4 * (size_t)WAVE * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->dbg_buf, 8 * (64 + 4 * 4096)))) return rc;
   HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
   if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64 + (size_t)h->m[1] * h->m[2])))) return rc;
@@ -648,7 +675,7 @@ int nl_debug_occupancy(int32_t out[8]) {
 
 int nl_get_build_info(nl_handle_t h, int32_t info[4]) {
   if (!h || !info) return NL_ERR_ARG;
-  info[0] = h->b_use_masks ? 1 : 0;
+  info[0] = h->b_use_mfma ? 2 : h->b_use_masks ? 1 : 0;
   info[1] = h->sweep_variant;
   info[2] = h->dtype == NL_F32 ? SweepCfg<float>::CAP : SweepCfg<double>::CAP;
   info[3] = h->num_cus;

@@ -496,6 +496,9 @@ template <typename T> struct SweepArgs {
   const int64_t* __restrict__ total;
   int64_t capacity;
   uint32_t* __restrict__ status;
+  T ms[3];                        // cell edge rounded to T (neighlist_cpu.hpp:404-406); k_sweep_mfma_f32 only
+  T delta;                        // k_sweep_mfma_f32: |r2 - rc2| below this is re-tested exactly
+  int32_t z_origin;               // global z layer of local layer 0
   uint32_t* __restrict__ masks;  // [n][64]: bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
   int32_t dbg;  // diagnostics only (NL_DEBUG_FLAGS): 1 = skip the search, 2 = skip the staging copy; 0 in production
@@ -602,6 +605,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
 // s < NSEG, segment s of the stencil stream (start in the sorted array, length, offset in the stream).
 struct CellCtx {
   int32_t ibeg, ni, seg_src, seg_len, seg_off, total_j;
+  int32_t cx, cy, cz;  // the i-cell (cz: local layer)
 };
 
 // Maps the workgroup to its i-cell (XCD-aware) and loads the segment table.  Returns false for an empty cell.
@@ -618,6 +622,7 @@ template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs
   const int32_t cell = cx + (cy + cz * a.my) * a.mx;
   c.ibeg = a.cell_start[cell];
   c.ni = a.cell_start[cell + 1] - c.ibeg;
+  c.cx = cx, c.cy = cy, c.cz = cz;
 
   // (the empty-cell exit comes after the segment-table loads so that both round trips are in flight together)
   // Segment table, one segment per lane (lanes >= 18 hold empty segments): 9 (dz,dy) rows x 2 x-parts.
@@ -784,7 +789,13 @@ __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan ov
 
 constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
 
-template <typename T>
+// Hit-word layouts.  MASK_LANE64 (search_group): 64 words per row, word l, bit t  <->  staged particle t*64 + l.
+// MASK_TILE16 (k_sweep_mfma_f32): 48 words per row, word g*16 + lam, bit 31 - b  <->  staged particle
+// (32 g + b)*16 + lam (16-particle tiles, 32 tiles per word group).
+enum { MASK_LANE64 = 0, MASK_TILE16 = 1 };
+constexpr int MASK16_WORDS = 48;
+
+template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(EXPAND_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
@@ -818,7 +829,10 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const int32_t slot = c.ibeg + min(r0 + u, c.ni - 1);
-      w[u] = a.masks[(size_t)slot * WAVE + lane];
+      if (LAYOUT == MASK_LANE64)
+        w[u] = a.masks[(size_t)slot * WAVE + lane];
+      else
+        w[u] = lane < MASK16_WORDS ? a.masks[(size_t)slot * MASK16_WORDS + lane] : 0u;
       base[u] = base_sorted[slot];  // (k_row_base: one gather kernel is cheaper than two dependent loads here)
     }
   };
@@ -842,7 +856,8 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   }
   __syncthreads();  // ids staged
 
-  const int32_t* const g = gids + lane;
+  // lane -> address of the particle of its word's first bit (LANE64: lowest bit first; TILE16: highest bit first)
+  const int32_t* const g = LAYOUT == MASK_LANE64 ? gids + lane : gids + (lane >> 4) * (32 * 16) + (lane & 15);
   for (int32_t r0 = r_beg; r0 < r_end; r0 += RB) {
     if (r0 != r_beg) load_rows(r0);  // dense cells only
     // four rows are expanded together: their LDS reads and stores are independent, so one trip through the
@@ -864,15 +879,22 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           on[q] = word[q] != 0;
-          const int32_t t = on[q] ? __ffs(word[q]) - 1 : 0;
-          val[q] = g[t * WAVE];  // unconditional read of a valid slot: the four reads go out back to back
+          // unconditional read of a valid slot: the four reads go out back to back
+          if (LAYOUT == MASK_LANE64) {
+            const int32_t t = on[q] ? __ffs(word[q]) - 1 : 0;
+            val[q] = g[t * WAVE];
+          } else {
+            const int32_t t = on[q] ? __clz(word[q]) : 0;
+            val[q] = g[t * 16];
+            if (on[q]) word[q] ^= 0x80000000u >> t;
+          }
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           if (on[q]) {
             *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + ((size_t)ptr[q] << 2)) = val[q];
             ptr[q]++;
-            word[q] &= word[q] - 1;
+            if (LAYOUT == MASK_LANE64) word[q] &= word[q] - 1;
           }
         }
       }
@@ -883,3 +905,4 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
 }  // namespace nl
 
 #include "nl_sweep_p.hpp"
+#include "nl_sweep_mfma.hpp"

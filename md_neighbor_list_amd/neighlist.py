@@ -200,10 +200,11 @@ class NeighListGPU:
 
 
     def build_info(self):
-        """{'masks': bool, 'variant': int, 'lds_batch': int, 'cus': int} of the last build."""
+        """{'masks': bool, 'mfma': bool, 'variant': int, 'lds_batch': int, 'cus': int} of the last build
+        (masks: the list was expanded from hit masks; mfma: those came from the matrix-core search)."""
         info = (C.c_int32 * 4)()
         check(self._lib.nl_get_build_info(self._h, C.byref(info)), "nl_get_build_info")
-        return {"masks": bool(info[0]), "variant": int(info[1]), "lds_batch": int(info[2]), "cus": int(info[3])}
+        return {"masks": bool(info[0]), "mfma": int(info[0]) == 2, "variant": int(info[1]), "lds_batch": int(info[2]), "cus": int(info[3])}
 
     def profile_last_build(self, reps=10):
         """Same for the last build (also a slab build); its position/id tensors are kept alive by this object."""

@@ -207,3 +207,42 @@ def test_baseline_sizes_known_answers(key):
         r2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
         want = np.nonzero(~(r2.astype(np.float64) > rc2) & (np.arange(len(q)) > i))[0]
         assert np.array_equal(np.sort(sl[kp[i]:kp[i + 1]]), want.astype(np.int32))
+
+
+@pytest.mark.parametrize("variant,binning", [(1, 0), (2, 0), (3, 0), (4, 0), (4, 1), (1, 1)])
+def test_every_sweep_variant_and_binning_path(variant, binning, monkeypatch):
+    """The non-default kernels stay correct: NL_SWEEP_VARIANT 1 (COUNT + FILL sweeps), 2 (persistent LDS-DMA),
+    3 (VALU hit masks, default), 4 (matrix-core hit masks); NL_BINNING=1 (atomic-rank hash/reorder)."""
+    monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
+    monkeypatch.setenv("NL_BINNING", str(binning))
+    for n, box, rc, seed in [(50000, (36.84, 36.84, 36.84), 3.3, 41), (9000, (25.0, 14.0, 19.0), 3.1, 42)]:
+        q, box = inputs.uniform_box(n, dtype=np.float32, seed=seed, box=box)
+        ref = _po().build(q, rc, box)
+        nl, nop, kp, sl = gpu_build(q, rc, box)
+        assert nl.build_info()["variant"] == variant
+        assert int(kp[-1]) == ref.npairs
+        assert np.array_equal(nop, ref.number_of_partners)
+        assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+
+
+@pytest.mark.parametrize("variant", [3, 4])
+def test_pairs_at_the_cutoff_fp32(variant, monkeypatch):
+    """Partners placed at distance rc*(1 +- k ulp) around random centres: every one of them falls inside the band
+    that the matrix-core search (k_sweep_mfma_f32, variant 4) must re-test with the reference's exact fp32
+    expression; variant 3 tests them with that expression directly."""
+    monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
+    rng = np.random.default_rng(77)
+    rc, L = 3.3, 40.0
+    nc = 6000
+    centres = rng.uniform(4.0, L - 4.0, size=(nc, 3))
+    d = rng.normal(size=(nc, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    scale = 1.0 + rng.integers(-6, 7, size=(nc, 1)) * 2.0 ** -23
+    q = np.concatenate([centres, centres + d * rc * scale]).astype(np.float32)
+    q = q[rng.permutation(len(q))]
+    box = (L, L, L)
+    ref = _po().build(q, rc, box)
+    _, nop, kp, sl = gpu_build(q, rc, box)
+    assert int(kp[-1]) == ref.npairs
+    assert np.array_equal(nop, ref.number_of_partners)
+    assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)

@@ -29,6 +29,10 @@ run() {  # run <seconds> <logfile> cmd...
 for s in $STEPS; do
   case $s in
     smoke) run 300 "$OUT/smoke.log" python -c "import __graft_entry__ as g; g.smoke()"; tail -3 "$OUT/smoke.log" ;;
+    mfbench) run 120 "$OUT/mfma_bench.log" ./tools/mfma_bench; cat "$OUT/mfma_bench.log" ;;
+    mfcheck) run 60 "$OUT/mfma_check.log" ./tools/mfma_check; cat "$OUT/mfma_check.log" ;;
+    dbgpar) run 300 "$OUT/debug_parity.log" python tools/debug_parity.py; cat "$OUT/debug_parity.log" ;;
+    stages) run 300 "$OUT/stages.log" python tools/stage_times.py; cat "$OUT/stages.log" ;;
     sbench) run 120 "$OUT/search_bench.log" ./tools/search_bench; cat "$OUT/search_bench.log" ;;
     micro) run 120 "$OUT/microbench.log" ./tools/microbench; cat "$OUT/microbench.log" ;;
     tests) run 900 "$OUT/pytest_gpu.log" python -m pytest tests -m gpu -q -x --durations=8; tail -25 "$OUT/pytest_gpu.log" ;;
