@@ -236,7 +236,7 @@ template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) 
     if (mode == MODE_COUNT) {
       if constexpr (sizeof(T) == 4) {
         if (h->b_use_mfma)
-          hipLaunchKernelGGL(k_sweep_mfma_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+          hipLaunchKernelGGL(k_sweep_mfma_f32, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
         else
           hipLaunchKernelGGL(k_sweep_count_masks_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
       } else

@@ -794,6 +794,7 @@ constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 work
 // (32 g + b)*16 + lam (16-particle tiles, 32 tiles per word group).
 enum { MASK_LANE64 = 0, MASK_TILE16 = 1 };
 constexpr int MASK16_WORDS = 48;
+constexpr int MASK16_MAX_ROWS = 64;  // cells with more rows have no masks on the TILE16 path (searched again by k_fill_masks)
 
 template <typename T, int LAYOUT>
 __global__ void __launch_bounds__(EXPAND_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
@@ -801,7 +802,13 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
   constexpr int EW = EXPAND_WAVES;
   // 5 KiB: ids only, so many workgroups per CU keep enough loads in flight
-  __shared__ __attribute__((aligned(32))) int32_t gids[CAP];
+  // MASK_TILE16 keeps the ids permuted so that lane l always reads bank l (as LANE64 does by construction):
+  // staged particle (32 g + b)*16 + lam  ->  index b*64 + g*16 + lam, 32 x 64 entries
+  constexpr int NGID = LAYOUT == MASK_LANE64 ? CAP : (CAP > 2048 ? CAP : 2048);
+  __shared__ __attribute__((aligned(32))) int32_t gids[NGID];
+  auto gslot = [](int32_t p) {
+    return LAYOUT == MASK_LANE64 ? p : ((p >> 4) & 31) * 64 + (p >> 9) * 16 + (p & 15);
+  };
   if (a.total[0] > a.capacity) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
     return;
@@ -809,7 +816,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   CellCtx c;
   if (!cell_setup(a, lane, c)) return;
-  if (c.total_j > CAP) {
+  if (c.total_j > CAP || (LAYOUT == MASK_TILE16 && c.ni > MASK16_MAX_ROWS)) {
     // No masks for this cell (its stencil needed several LDS batches in COUNT_MASKS): search it again, as
     // k_sweep<FILL> does, in small batches through the id buffer.  Rare (very dense cells only).
     constexpr int CAPS = (int)(CAP * sizeof(int32_t) / (sizeof(Pos<T>))) / WAVE * WAVE;
@@ -850,14 +857,14 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
       const bool p1 = k1 < len;
       const int32_t v0 = a.sorted[src + k].gid;
       const int32_t v1 = a.sorted[src + (p1 ? k1 : k)].gid;
-      gids[off + k] = v0;
-      if (p1) gids[off + k1] = v1;
+      gids[gslot(off + k)] = v0;
+      if (p1) gids[gslot(off + k1)] = v1;
     }
   }
   __syncthreads();  // ids staged
 
   // lane -> address of the particle of its word's first bit (LANE64: lowest bit first; TILE16: highest bit first)
-  const int32_t* const g = LAYOUT == MASK_LANE64 ? gids + lane : gids + (lane >> 4) * (32 * 16) + (lane & 15);
+  const int32_t* const g = gids + lane;
   for (int32_t r0 = r_beg; r0 < r_end; r0 += RB) {
     if (r0 != r_beg) load_rows(r0);  // dense cells only
     // four rows are expanded together: their LDS reads and stores are independent, so one trip through the
@@ -885,7 +892,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
             val[q] = g[t * WAVE];
           } else {
             const int32_t t = on[q] ? __clz(word[q]) : 0;
-            val[q] = g[t * 16];
+            val[q] = g[t * WAVE];
             if (on[q]) word[q] ^= 0x80000000u >> t;
           }
         }

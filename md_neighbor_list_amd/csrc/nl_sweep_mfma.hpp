@@ -17,12 +17,13 @@
 // accumulator (sign = accepted), and one v_alignbit that shifts the sign bit into the lane's hit word.  No scalar bookkeeping per test: the counts are
 // popcounts of the hit words at the end.
 //
-// Work split: a workgroup (4 waves) owns an i-cell as in k_sweep.  The stencil stream is staged ONCE into LDS as
-// four component arrays (ux, uy, uz, |u|^2) + ids.  Every wave handles ALL i-blocks (16 rows each, up to 3 at a
-// time) against a contiguous quarter of the j-tiles (16 particles each), so each B operand fetched from LDS feeds
-// up to 3 MFMAs.  Hit words (layout MASK_TILE16, 48 per row): word (t / 32)*16 + lam, bit 31 - t % 32 for tile t and
-// lam = j % 16.  The waves OR their parts into a row-major LDS image, which leaves as one contiguous block (the
-// rows of a cell are consecutive sorted slots); k_fill_masks<T, MASK_TILE16> expands them.
+// Work split: a workgroup of 6 waves owns an i-cell.  The stencil stream is staged ONCE into LDS as four component
+// arrays (ux, uy, uz, |u|^2) + ids (26 KB: five workgroups = 30 waves per CU).  A unit of work is one i-block (16
+// rows) against one half of the j-tiles (16 particles each): tiles [0, 32) or [32, ntiles); a cell of 33..48 rows has
+// six units, one per wave.  Little per-wave state (one MFMA accumulator pair, 4 row constants, 4 hit words).
+// Hit words (layout MASK_TILE16, 48 per row): word (t / 32)*16 + lam, bit 31 - t % 32 for tile t and lam = j % 16;
+// the halves meet at a word boundary, so every word has one writer and goes straight to memory in 64-byte pieces.
+// k_fill_masks<T, MASK_TILE16> expands them.
 #pragma once
 
 namespace nl {
@@ -32,25 +33,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MF_CAP = SweepCfg<float>::CAP;  // staged particles per cell: the same single-batch limit as the masks
 constexpr int MF_CSTR = MF_CAP + 16;          // component array stride: the four bases fall on banks 0, 16, 32, 48
 constexpr int MF_TILE = 16;
-constexpr int MF_NBMAX = 3;                   // i-blocks (of 16 rows) searched together (mf_rows<1..3>)
-constexpr int MF_ROWS = MF_NBMAX * 16;        // rows per pass
+constexpr int MF_WAVES = 6;                   // waves per workgroup
+constexpr int MF_ROWS = 64;                   // most rows a cell may have on this path (k_fill_masks knows this too)
 constexpr int MF_WORDS = (MF_CAP / MF_TILE + 31) / 32 * 16;  // hit words per row: 3 groups of 32 tiles x 16 lanes = 48
 
 struct MfmaLds {
   float comp[4 * MF_CSTR];  // ux | uy | uz | |u|^2 of the staged stream
   int32_t gid[MF_CAP];
   int32_t cnt[MF_ROWS];
-  uint32_t words[MF_ROWS * MF_WORDS];  // hit words of the pass, row-major: leave the kernel as one contiguous block
 };
 static_assert(sizeof(float) * 4 * MF_CSTR >= sizeof(Pos<float>) * SweepCfg<float>::CAP, "fallback tile fits");
-static_assert(MF_WORDS == MASK16_WORDS && MF_WORDS <= WAVE, "k_fill_masks<MASK_TILE16> reads one word per lane");
-
-// first tile and number of tiles of wave w when ntiles are dealt to SWEEP_WAVES waves in contiguous runs
-__device__ __forceinline__ void mf_tile_range(int32_t ntiles, int32_t w, int32_t& t_beg, int32_t& nt) {
-  const int32_t base = ntiles / SWEEP_WAVES, rem = ntiles % SWEEP_WAVES;
-  t_beg = w * base + min(w, rem);
-  nt = base + (w < rem ? 1 : 0);
-}
+static_assert(MF_WORDS == MASK16_WORDS && MF_WORDS == 48 && MF_ROWS == MASK16_MAX_ROWS, "layout shared with k_fill_masks");
 
 // stream position -> index in the sorted array (walks the 18-entry segment table held one entry per lane)
 __device__ __forceinline__ int32_t mf_stream_to_sorted(const CellCtx& c, int32_t p) {
@@ -63,56 +56,46 @@ __device__ __forceinline__ int32_t mf_stream_to_sorted(const CellCtx& c, int32_t
   return idx;
 }
 
-// NB i-blocks starting at row i0 of the cell against tiles [t_beg, t_beg + nt) of the staged stream.
+// One unit: the i-block of 16 rows starting at row i0 of the cell against half `half` of the ntiles staged tiles.
 // i_off: stream position of the cell's own first particle (the i-particles are part of their own stencil, so their
 // local coordinates and ids are already in LDS).
-template <int NB>
-__device__ __forceinline__ void mf_rows(const SweepArgs<float>& a, const CellCtx& c, MfmaLds& L, int lane,
-                                        int32_t i_off, int32_t i0, int32_t t_beg, int32_t nt) {
+__device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx& c, MfmaLds& L, int lane,
+                                        int32_t i_off, int32_t i0, int32_t half, int32_t ntiles) {
   const int kq = lane >> 4, lam = lane & 15;
-  float A[NB];
-  f32x4 C[NB];
-  int32_t gi[NB][4];
-  uint32_t bits[NB][4];
+  float A;
+  f32x4 C;
+  int32_t gi[4];
+  {
+    const int32_t irow = i0 + lam;
+    const float u = L.comp[min(kq, 2) * MF_CSTR + i_off + min(irow, c.ni - 1)];
+    A = irow < c.ni ? (kq == 3 ? 1.0f : mul_rn(-2.0f, u)) : 0.0f;
+  }
 #pragma unroll
-  for (int b = 0; b < NB; b++) {
-    {
-      const int32_t irow = i0 + 16 * b + lam;
-      const float u = L.comp[min(kq, 2) * MF_CSTR + i_off + min(irow, c.ni - 1)];
-      A[b] = irow < c.ni ? (kq == 3 ? 1.0f : mul_rn(-2.0f, u)) : 0.0f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int32_t irow = i0 + 16 * b + 4 * kq + r;
-      const int32_t p = i_off + min(irow, c.ni - 1);
-      C[b][r] = irow < c.ni ? sub_rn(L.comp[3 * MF_CSTR + p], a.rc2) : 1.0e30f;  // padding rows: never accepted
-      gi[b][r] = L.gid[p];
-      bits[b][r] = 0;
-    }
+  for (int r = 0; r < 4; r++) {
+    const int32_t irow = i0 + 4 * kq + r;
+    const int32_t p = i_off + min(irow, c.ni - 1);
+    C[r] = irow < c.ni ? sub_rn(L.comp[3 * MF_CSTR + p], a.rc2) : 1.0e30f;  // padding rows: never accepted
+    gi[r] = L.gid[p];
   }
 
   const float* const bp = L.comp + kq * MF_CSTR + lam;
   const int32_t* const gp = L.gid + lam;
   const float delta = a.delta;
-  const int32_t t_last = t_beg + nt - 1;
+  uint32_t bits[4];
 
   // One tile's accumulators -> one more bit in every hit word.
-  auto process = [&](const f32x4 (&acc)[NB], int32_t gj, int32_t t) {
+  auto process = [&](const f32x4& acc, int32_t gj, int32_t t) {
     // smallest |r2 - rc2| of the tile in this lane: v_min3_f32 with |.| source modifiers, half an instruction per value
-    float m = __builtin_fabsf(acc[0][0]);
+    float m = __builtin_huge_valf();
 #pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-      for (int r = (b == 0 ? 1 : 0); r < 4; r++) m = __builtin_fminf(m, __builtin_fabsf(acc[b][r]));
+    for (int r = 0; r < 4; r++) m = __builtin_fminf(m, __builtin_fabsf(acc[r]));
     // sign(acc) = accepted by distance, sign(gid_i - gid_j) = j is the upper index (ids are >= 0)
 #pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const float av = acc[b][r];  // (bit_cast straight from the vector element picks element 0)
-        const uint32_t h = __float_as_uint(av) & (uint32_t)(gi[b][r] - gj);
-        bits[b][r] = __builtin_amdgcn_alignbit(bits[b][r], h, 31);  // (bits << 1) | (h >> 31)
-      }
+    for (int r = 0; r < 4; r++) {
+      const float av = acc[r];  // (bit_cast straight from the vector element picks element 0)
+      const uint32_t h = __float_as_uint(av) & (uint32_t)(gi[r] - gj);
+      bits[r] = __builtin_amdgcn_alignbit(bits[r], h, 31);  // (bits << 1) | (h >> 31)
+    }
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(m < delta) != 0, 0)) {
       // rare (about 1 % of the tiles): some |r2 - rc2| is inside the error band of the matrix-core expression.
       // Re-test those elements with the reference's expression on the original coordinates and flip the bit just
@@ -122,68 +105,68 @@ __device__ __forceinline__ void mf_rows(const SweepArgs<float>& a, const CellCtx
       const bool jok = pj_pos < c.total_j;
       const Pos<float> pj = a.sorted[jok ? mf_stream_to_sorted(c, pj_pos) : c.ibeg];
 #pragma unroll
-      for (int b = 0; b < NB; b++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int32_t irow = i0 + 16 * b + 4 * kq + r;
-          const float av = acc[b][r];
-          if (__builtin_fabsf(av) < delta && jok && irow < c.ni) {
-            const Pos<float> pi = a.sorted[c.ibeg + irow];
-            const float dx = sub_rn(pj.x, pi.x), dy = sub_rn(pj.y, pi.y), dz = sub_rn(pj.z, pi.z);
-            const float r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-            const bool want = !(r2 > a.rc2), have = (__float_as_uint(av) >> 31) != 0;
-            if (want != have && gi[b][r] < gj) bits[b][r] ^= 1u;
-            if (a.dbg & 8) atomicAdd(a.dbg_buf + 0, 1ull);
-          }
+      for (int r = 0; r < 4; r++) {
+        const int32_t irow = i0 + 4 * kq + r;
+        const float av = acc[r];
+        if (__builtin_fabsf(av) < delta && jok && irow < c.ni) {
+          const Pos<float> pi = a.sorted[c.ibeg + irow];
+          const float dx = sub_rn(pj.x, pi.x), dy = sub_rn(pj.y, pi.y), dz = sub_rn(pj.z, pi.z);
+          const float r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+          const bool want = !(r2 > a.rc2), have = (__float_as_uint(av) >> 31) != 0;
+          if (want != have && gi[r] < gj) bits[r] ^= 1u;
+          if (a.dbg & 8) atomicAdd(a.dbg_buf + 0, 1ull);
         }
+      }
     }
   };
 
-  if (nt > 0) {
-    // Two accumulator sets in ping-pong: the MFMAs of the next tile are issued before the vector work of the
-    // current one, so the matrix pipe runs underneath it.  Tile indices beyond the wave's share are clamped (the
-    // result of such an MFMA is never consumed).
-    auto tix = [&](int32_t t) { return min(t, t_last) * MF_TILE; };
-    float bv0 = bp[tix(t_beg)], bv1 = bp[tix(t_beg + 1)];
-    int32_t g0 = gp[tix(t_beg)], g1 = gp[tix(t_beg + 1)];
-    f32x4 acc0[NB], acc1[NB];
+  // Word group g = tiles [32 g, 32 g + n): search them into `bits` (nothing to do for n <= 0), store the group's
+  // words of the block's rows, add their popcounts to `total`.
+  int32_t total[4] = {0, 0, 0, 0};
+  auto run = [&](int32_t g, int32_t n) {
 #pragma unroll
-    for (int b = 0; b < NB; b++) acc0[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b], bv0, C[b], 0, 0, 0);
-    for (int32_t t = t_beg; t <= t_last; t += 2) {
+    for (int r = 0; r < 4; r++) bits[r] = 0;
+    if (n > 0) {
+      const int32_t tb = 32 * g, t_last = tb + n - 1;
+      // Two accumulators in ping-pong: the MFMA of the next tile is issued before the vector work of the current
+      // one.  Tile indices beyond the run are clamped (the result of such an MFMA is never consumed).
+      auto tix = [&](int32_t t) { return min(t, t_last) * MF_TILE; };
+      float bv0 = bp[tix(tb)], bv1 = bp[tix(tb + 1)];
+      int32_t g0 = gp[tix(tb)], g1 = gp[tix(tb + 1)];
+      f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, bv0, C, 0, 0, 0), acc1;
+      for (int32_t t = tb; t <= t_last; t += 2) {
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, bv1, C, 0, 0, 0);
+        bv0 = bp[tix(t + 2)];
+        const int32_t g0n = gp[tix(t + 2)];
+        process(acc0, g0, t);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, bv0, C, 0, 0, 0);
+        bv1 = bp[tix(t + 3)];
+        const int32_t g1n = gp[tix(t + 3)];
+        if (t + 1 <= t_last) process(acc1, g1, t + 1);
+        g0 = g0n, g1 = g1n;
+      }
+      const uint32_t up = 32u - (uint32_t)n;  // first tile of the group -> bit 31
 #pragma unroll
-      for (int b = 0; b < NB; b++) acc1[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b], bv1, C[b], 0, 0, 0);
-      bv0 = bp[tix(t + 2)];
-      const int32_t g0n = gp[tix(t + 2)];
-      process(acc0, g0, t);
-#pragma unroll
-      for (int b = 0; b < NB; b++) acc0[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[b], bv0, C[b], 0, 0, 0);
-      bv1 = bp[tix(t + 3)];
-      const int32_t g1n = gp[tix(t + 3)];
-      if (t + 1 <= t_last) process(acc1, g1, t + 1);
-      g0 = g0n, g1 = g1n;
+      for (int r = 0; r < 4; r++) bits[r] <<= up;
     }
-  }
-
-  // Deposit the hit words in the row-major LDS image (tile t -> group t / 32, bit 31 - t % 32: a wave's share
-  // spans at most two groups) and add the popcounts to the row counts.
-  const uint32_t sh_hi = 64u - (uint32_t)nt, sh_lo = (uint32_t)t_beg & 31u;
-  const int32_t grp = t_beg >> 5;
-#pragma unroll
-  for (int b = 0; b < NB; b++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const int32_t lrow = 16 * b + 4 * kq + r;
-      const uint64_t v64 = nt > 0 ? ((uint64_t)bits[b][r] << sh_hi) >> sh_lo : 0ull;
-      const uint32_t hi = (uint32_t)(v64 >> 32), lo = (uint32_t)v64;
-      if (hi) atomicOr(&L.words[lrow * MF_WORDS + grp * 16 + lam], hi);
-      if (lo) atomicOr(&L.words[lrow * MF_WORDS + (grp + 1) * 16 + lam], lo);
-      int32_t v = __popc(hi) + __popc(lo);
-      v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1 within the 16 lanes of a row group
-      v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
-      v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
-      v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
-      if (lam == 15 && v) atomicAdd(&L.cnt[lrow], v);
+      const int32_t irow = i0 + 4 * kq + r;
+      if (irow < c.ni) a.masks[(size_t)(c.ibeg + irow) * MF_WORDS + g * 16 + lam] = bits[r];
+      total[r] += __popc(bits[r]);
     }
+  };
+  // half 0: word group 0; half 1: word groups 1 and 2 (one instance of the loop body for all three)
+  for (int32_t g = half; g < 1 + 2 * half; g++) run(g, a.dbg & 1 ? 0 : min(32, ntiles - 32 * g));
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int32_t v = total[r];
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1 within the 16 lanes of a row group
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    if (lam == 15 && v) atomicAdd(&L.cnt[i0 + 4 * kq + r], v);
+  }
 }
 
 // diagnostics (NL_DEBUG_FLAGS & 4): thread 0 records the cycles since the previous stamp in the workgroup's
@@ -197,7 +180,7 @@ __device__ __forceinline__ void mf_stamp(const SweepArgs<float>& a, int tid, int
   }
 }
 
-__global__ void __launch_bounds__(SWEEP_WAVES* WAVE, 4) k_sweep_mfma_f32(SweepArgs<float> a) {
+__global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f32(SweepArgs<float> a) {
   __shared__ __attribute__((aligned(16))) MfmaLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned long long t_prev = 0;
@@ -205,9 +188,11 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE, 4) k_sweep_mfma_f32(SweepAr
   CellCtx c;
   if (!cell_setup(a, lane, c)) return;
   mf_stamp(a, tid, 0, t_prev);  // cell table
-  if (c.total_j > MF_CAP) {
-    // stencil larger than one LDS batch: counts only, by the VALU search (k_fill_masks searches such cells again)
-    cell_search<float, MODE_COUNT>(a, c, reinterpret_cast<Pos<float>*>(L.comp), tid, lane, wave);
+  if (c.total_j > MF_CAP || c.ni > MF_ROWS) {
+    // stencil larger than one LDS batch (or a very full cell): counts only, by the VALU search; k_fill_masks
+    // searches such cells again
+    cell_search<float, MODE_COUNT, SweepCfg<float>::CAP, MF_WAVES>(a, c, reinterpret_cast<Pos<float>*>(L.comp), tid, lane,
+                                                                   wave);
     return;
   }
   // centre of the i-cell: the origin of the local coordinates (any point near the cell would do)
@@ -223,30 +208,35 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE, 4) k_sweep_mfma_f32(SweepAr
                 : __builtin_amdgcn_readlane(c.seg_off, 13) + (c.ibeg - __builtin_amdgcn_readlane(c.seg_src, 13));
   }
 
-  // ---- stage the stream as component arrays
-  for (int32_t sg = wave; sg < NSEG; sg += SWEEP_WAVES) {
-    const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
-    if (len == 0) continue;
-    const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
-    const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg);
-    if (a.dbg & 2) continue;  // diagnostics: no staging copies
-    for (int32_t k = lane; k < len; k += 2 * WAVE) {
-      const int32_t k1 = k + WAVE;
-      const bool p1 = k1 < len;
-      const Pos<float> v0 = a.sorted[src + k];
-      const Pos<float> v1 = a.sorted[src + (p1 ? k1 : k)];
-      {
-        const float ux = sub_rn(v0.x, ccx), uy = sub_rn(v0.y, ccy), uz = sub_rn(v0.z, ccz);
-        L.comp[off + k] = ux, L.comp[MF_CSTR + off + k] = uy, L.comp[2 * MF_CSTR + off + k] = uz;
-        L.comp[3 * MF_CSTR + off + k] = add_rn(add_rn(mul_rn(ux, ux), mul_rn(uy, uy)), mul_rn(uz, uz));
-        L.gid[off + k] = v0.gid;
-      }
-      if (p1) {
-        const float ux = sub_rn(v1.x, ccx), uy = sub_rn(v1.y, ccy), uz = sub_rn(v1.z, ccz);
-        L.comp[off + k1] = ux, L.comp[MF_CSTR + off + k1] = uy, L.comp[2 * MF_CSTR + off + k1] = uz;
-        L.comp[3 * MF_CSTR + off + k1] = add_rn(add_rn(mul_rn(ux, ux), mul_rn(uy, uy)), mul_rn(uz, uz));
-        L.gid[off + k1] = v1.gid;
-      }
+  // ---- stage the stream as component arrays.  Wave w copies segments w, w + 6, w + 12; the loads of the first
+  // 192 particles of each are all issued before the first LDS write (one memory round trip per cell, not one
+  // per 128 particles); longer segments (dense cells) finish in a plain loop.
+  auto put = [&](int32_t p, const Pos<float>& v) {
+    const float ux = sub_rn(v.x, ccx), uy = sub_rn(v.y, ccy), uz = sub_rn(v.z, ccz);
+    L.comp[p] = ux, L.comp[MF_CSTR + p] = uy, L.comp[2 * MF_CSTR + p] = uz;
+    L.comp[3 * MF_CSTR + p] = add_rn(add_rn(mul_rn(ux, ux), mul_rn(uy, uy)), mul_rn(uz, uz));
+    L.gid[p] = v.gid;
+  };
+  if (!(a.dbg & 2)) {
+    constexpr int NS = (NSEG + MF_WAVES - 1) / MF_WAVES, NK = 3;
+    int32_t len[NS], src[NS], off[NS];
+    Pos<float> v[NS][NK];
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+      const int sg = wave + q * MF_WAVES;  // wave-uniform; < 32, lanes >= NSEG hold empty segments
+      len[q] = __builtin_amdgcn_readlane(c.seg_len, sg);
+      src[q] = __builtin_amdgcn_readlane(c.seg_src, sg);
+      off[q] = __builtin_amdgcn_readlane(c.seg_off, sg);
+#pragma unroll
+      for (int k = 0; k < NK; k++)
+        if (k * WAVE < len[q]) v[q][k] = a.sorted[src[q] + min(k * WAVE + lane, len[q] - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+#pragma unroll
+      for (int k = 0; k < NK; k++)
+        if (k * WAVE + lane < len[q]) put(off[q] + k * WAVE + lane, v[q][k]);
+      for (int32_t k = NK * WAVE + lane; k < len[q]; k += WAVE) put(off[q] + k, a.sorted[src[q] + k]);
     }
   }
   {  // sentinels up to the next tile boundary: |u|^2 = 1e30, never accepted, never uncertain
@@ -257,42 +247,19 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE, 4) k_sweep_mfma_f32(SweepAr
       L.gid[pad] = 0;
     }
   }
-  uint4* const words4 = reinterpret_cast<uint4*>(L.words);
-  constexpr int NW4 = MF_ROWS * MF_WORDS / 4;
-  for (int k = tid; k < NW4; k += SWEEP_WAVES * WAVE) words4[k] = make_uint4(0, 0, 0, 0);
   if (tid < MF_ROWS) L.cnt[tid] = 0;
   mf_stamp(a, tid, 1, t_prev);  // staging (this wave's share: loads returned, LDS written)
   __syncthreads();
   mf_stamp(a, tid, 2, t_prev);  // barrier
 
   const int32_t ntiles = (c.total_j + MF_TILE - 1) / MF_TILE;
-  int32_t t_beg, nt;
-  mf_tile_range(ntiles, wave, t_beg, nt);
-  if (a.dbg & 1) nt = 0;  // diagnostics: staging, row setup and mask stores only
-  for (int32_t i0 = 0; i0 < c.ni; i0 += MF_ROWS) {
-    const int32_t rows = min(MF_ROWS, c.ni - i0);
-    switch ((rows + 15) >> 4) {
-      case 1: mf_rows<1>(a, c, L, lane, i_off, i0, t_beg, nt); break;
-      case 2: mf_rows<2>(a, c, L, lane, i_off, i0, t_beg, nt); break;
-      default: mf_rows<3>(a, c, L, lane, i_off, i0, t_beg, nt); break;
-    }
-    mf_stamp(a, tid, 3, t_prev);  // search + deposit
-    __syncthreads();
-    mf_stamp(a, tid, 4, t_prev);  // barrier
-    // the pass's rows are consecutive sorted slots: their hit words leave as one contiguous block
-    uint4* const out4 = reinterpret_cast<uint4*>(a.masks + (size_t)(c.ibeg + i0) * MF_WORDS);
-    const bool more = i0 + MF_ROWS < c.ni;
-    for (int k = tid; k < rows * (MF_WORDS / 4); k += SWEEP_WAVES * WAVE) {
-      out4[k] = words4[k];
-      if (more) words4[k] = make_uint4(0, 0, 0, 0);
-    }
-    if (tid < rows) {
-      a.count[a.sorted_row[c.ibeg + i0 + tid]] = L.cnt[tid];
-      L.cnt[tid] = 0;
-    }
-    mf_stamp(a, tid, 5, t_prev);  // stores (until acknowledged: only the diagnostic waits for them)
-    if (more) __syncthreads();
-  }
+  const int32_t nunits = 2 * ((c.ni + 15) >> 4);
+  for (int32_t u = wave; u < nunits; u += MF_WAVES) mf_unit(a, c, L, lane, i_off, (u >> 1) * 16, u & 1, ntiles);
+  mf_stamp(a, tid, 3, t_prev);  // search + word stores
+  __syncthreads();
+  mf_stamp(a, tid, 4, t_prev);  // barrier
+  if (tid < c.ni) a.count[a.sorted_row[c.ibeg + tid]] = L.cnt[tid];
+  mf_stamp(a, tid, 5, t_prev);  // counts
 }
 
 }  // namespace nl

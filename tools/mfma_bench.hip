@@ -1,4 +1,4 @@
-// tools/mfma_bench.hip -- isolates the tile loop of k_sweep_mfma_f32: every wave runs the REAL mf_rows<NB>
+// tools/mfma_bench.hip -- isolates the tile loop of k_sweep_mfma_f32: every wave runs the REAL mf_unit
 // (nl_sweep_mfma.hpp) on a resident LDS image of one synthetic cell (40 rows, 1056 staged particles = 66 tiles),
 // no staging, no global traffic, for many repetitions.  Reports shader cycles per (wave, tile) step per SIMD at
 // several occupancies; max over waves = throughput (the SIMD arbitrates oldest-first).
@@ -25,52 +25,53 @@ using namespace nl;
 
 constexpr int NJ = 1056, NI = 40, IOFF = 512;
 
-template <int NB>
-__global__ void __launch_bounds__(256, 4) kb(SweepArgs<float> a, int reps, unsigned long long* stamps, uint32_t* sink) {
+template <int NI>
+__global__ void __launch_bounds__(MF_WAVES * 64, 8) kb(SweepArgs<float> a, int reps, unsigned long long* stamps, uint32_t* sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
   MfmaLds& L = *reinterpret_cast<MfmaLds*>(raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float cc = 1.5f * 3.386f;
-  for (int k = tid; k < NJ; k += 256) {
+  for (int k = tid; k < NJ; k += MF_WAVES * 64) {
     const Pos<float> v = a.sorted[k];
     const float ux = v.x - cc, uy = v.y - cc, uz = v.z - cc;
     L.comp[k] = ux, L.comp[MF_CSTR + k] = uy, L.comp[2 * MF_CSTR + k] = uz;
     L.comp[3 * MF_CSTR + k] = ux * ux + uy * uy + uz * uz;
     L.gid[k] = v.gid;
   }
-  for (int k = tid; k < MF_ROWS * MF_WORDS; k += 256) L.words[k] = 0;
   if (tid < MF_ROWS) L.cnt[tid] = 0;
+
   __syncthreads();
   CellCtx c{};
-  c.ibeg = IOFF, c.ni = NB * 16 - 8, c.total_j = NJ;
+  c.ibeg = IOFF, c.ni = NI, c.total_j = NJ;
   c.seg_src = 0, c.seg_len = lane == 0 ? NJ : 0, c.seg_off = lane == 0 ? 0 : NJ;
-  int32_t t_beg, nt;
-  mf_tile_range(NJ / 16, wave, t_beg, nt);
+  const int32_t ntiles = NJ / 16, nunits = 2 * ((NI + 15) / 16);
   unsigned long long t0, t1;
   asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
-  for (int r = 0; r < reps; r++) mf_rows<NB>(a, c, L, lane, IOFF, 0, t_beg, nt);
+  for (int r = 0; r < reps; r++)
+    for (int32_t u = wave; u < nunits; u += MF_WAVES) mf_unit(a, c, L, lane, IOFF, (u >> 1) * 16, u & 1, ntiles);
   asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-  if (lane == 0) stamps[blockIdx.x * 4 + wave] = t1 - t0;
-  if (L.words[tid] == 0x12345678u) sink[0] = 1;
+  if (lane == 0) stamps[blockIdx.x * MF_WAVES + wave] = t1 - t0;
+  if (L.cnt[tid & 63] == 0x12345678) sink[0] = 1;
 }
 
-template <int NB> int run(const char* name, SweepArgs<float> a, unsigned long long* stamps_d, uint32_t* sink) {
+template <int NI> int run(const char* name, SweepArgs<float> a, unsigned long long* stamps_d, uint32_t* sink) {
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount, reps = 40;
-  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kb<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kb<NI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   printf("%-12s", name);
-  for (int bpc : {1, 2, 3, 4}) {
+  for (int bpc : {1, 2, 3, 4, 5}) {
     const size_t lds = (size_t)(160 * 1024 / bpc) & ~(size_t)1023;
-    const int blocks = cus * bpc, nw = blocks * 4;
-    hipLaunchKernelGGL((kb<NB>), dim3(blocks), dim3(256), lds, 0, a, 2, stamps_d, sink);
-    hipLaunchKernelGGL((kb<NB>), dim3(blocks), dim3(256), lds, 0, a, reps, stamps_d, sink);
+    const int blocks = cus * bpc, nw = blocks * MF_WAVES;
+    hipLaunchKernelGGL((kb<NI>), dim3(blocks), dim3(MF_WAVES * 64), lds, 0, a, 2, stamps_d, sink);
+    hipLaunchKernelGGL((kb<NI>), dim3(blocks), dim3(MF_WAVES * 64), lds, 0, a, reps, stamps_d, sink);
     CHK(hipDeviceSynchronize());
     std::vector<unsigned long long> st(nw);
     CHK(hipMemcpy(st.data(), stamps_d, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost));
     std::sort(st.begin(), st.end());
-    const double steps = (double)reps * (NJ / 16) / 4.0;  // tile steps per wave (16.5)
-    printf(" | w%d med %7.1f max %7.1f", bpc, (double)st[nw / 2] / (steps * bpc), (double)st[nw - 1] / (steps * bpc));
+    // MFMA steps (one 16 x 16 block of tests) per SIMD: workgroups per CU x i-blocks x 66 tiles / 4 SIMDs
+    const double steps = (double)reps * bpc * ((NI + 15) / 16) * (NJ / 16) / 4.0;
+    printf(" | %d wg/CU (%.1f waves/SIMD) max %6.1f", bpc, MF_WAVES * bpc / 4.0, (double)st[nw - 1] / steps);
   }
   printf("\n");
   return 0;
@@ -92,11 +93,13 @@ int main() {
   CHK(hipMemcpy(dj, hj.data(), sizeof(Pos<float>) * NJ, hipMemcpyHostToDevice));
   SweepArgs<float> a{};
   a.sorted = dj;
+  uint32_t* masks;
+  CHK(hipMalloc(&masks, sizeof(uint32_t) * MF_WORDS * (IOFF + MF_ROWS)));
+  a.masks = masks;  // (every workgroup writes the same rows: timing only)
   a.rc2 = 3.3f * 3.3f;
   a.delta = 3.5e-4f;
-  printf("mf_rows<NB> alone: shader cycles per tile step (NB MFMAs + their vector work) per SIMD; w = waves per SIMD\n");
-  run<1>("NB=1", a, stamps, sink);
-  run<2>("NB=2", a, stamps, sink);
-  run<3>("NB=3", a, stamps, sink);
+  printf("mf_unit alone: shader cycles per SIMD per MFMA step (one 16 x 16 block of tests: 1 MFMA + its vector work),\nlast wave to finish\n");
+  run<40>("40 rows", a, stamps, sink);
+  run<64>("64 rows", a, stamps, sink);
   return 0;
 }

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CHK(x)                                                                  \
@@ -121,6 +122,52 @@ __global__ void __launch_bounds__(1024) k(float* out, unsigned long long* stamps
                "v_cmp_nlt_f32 vcc, s46, v40\n v_cndmask_b32 v43, v53, v52, vcc\n v_cmp_lt_i32 vcc, s47, v43\n"
                "v_addc_co_u32 v44, vcc, 0, v44, vcc\n"
                ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "vcc");)
+    } else if (KIND == 20) {
+      REP8(asm volatile("v_alignbit_b32 %0, %0, %8, 31\n v_alignbit_b32 %1, %1, %8, 31\n v_alignbit_b32 %2, %2, %8, 31\n v_alignbit_b32 %3, %3, %8, 31\n"
+                        "v_alignbit_b32 %4, %4, %8, 31\n v_alignbit_b32 %5, %5, %8, 31\n v_alignbit_b32 %6, %6, %8, 31\n v_alignbit_b32 %7, %7, %8, 31\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+    } else if (KIND == 21) {
+      REP8(asm volatile("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n"
+                        "v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+    } else if (KIND == 22) {
+      REP8(asm volatile("v_sub_u32 %0, %0, %8\n v_sub_u32 %1, %1, %8\n v_sub_u32 %2, %2, %8\n v_sub_u32 %3, %3, %8\n"
+                        "v_sub_u32 %4, %4, %8\n v_sub_u32 %5, %5, %8\n v_sub_u32 %6, %6, %8\n v_sub_u32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+    } else if (KIND == 23) {
+      REP8(asm volatile("v_min3_f32 %0, %0, |%8|, |%1|\n v_min3_f32 %1, %1, |%8|, |%2|\n v_min3_f32 %2, %2, |%8|, |%3|\n v_min3_f32 %3, %3, |%8|, |%4|\n"
+                        "v_min3_f32 %4, %4, |%8|, |%5|\n v_min3_f32 %5, %5, |%8|, |%6|\n v_min3_f32 %6, %6, |%8|, |%7|\n v_min3_f32 %7, %7, |%8|, |%0|\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+    } else if (KIND == 24) {  // fp32 MFMA alone, 8 independent accumulators
+      REP8(asm volatile("v_mfma_f32_16x16x4_f32 v[60:63], v46, v47, v[56:59]\n v_mfma_f32_16x16x4_f32 v[64:67], v46, v47, v[56:59]\n"
+                        "v_mfma_f32_16x16x4_f32 v[68:71], v46, v47, v[56:59]\n v_mfma_f32_16x16x4_f32 v[72:75], v46, v47, v[56:59]\n"
+                        "v_mfma_f32_16x16x4_f32 v[76:79], v46, v47, v[56:59]\n v_mfma_f32_16x16x4_f32 v[80:83], v46, v47, v[56:59]\n"
+                        "v_mfma_f32_16x16x4_f32 v[84:87], v46, v47, v[56:59]\n v_mfma_f32_16x16x4_f32 v[88:91], v46, v47, v[56:59]\n"
+                        ::: "v46", "v47", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+                            "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");)
+    } else if (KIND == 25) {  // f16 MFMA alone
+      REP8(asm volatile("v_mfma_f32_16x16x32_f16 v[60:63], v[40:43], v[44:47], v[56:59]\n v_mfma_f32_16x16x32_f16 v[64:67], v[40:43], v[44:47], v[56:59]\n"
+                        "v_mfma_f32_16x16x32_f16 v[68:71], v[40:43], v[44:47], v[56:59]\n v_mfma_f32_16x16x32_f16 v[72:75], v[40:43], v[44:47], v[56:59]\n"
+                        "v_mfma_f32_16x16x32_f16 v[76:79], v[40:43], v[44:47], v[56:59]\n v_mfma_f32_16x16x32_f16 v[80:83], v[40:43], v[44:47], v[56:59]\n"
+                        "v_mfma_f32_16x16x32_f16 v[84:87], v[40:43], v[44:47], v[56:59]\n v_mfma_f32_16x16x32_f16 v[88:91], v[40:43], v[44:47], v[56:59]\n"
+                        ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+                            "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");)
+#define TILE_VALU(A0, A1, A2, A3)                                                                          \
+  "v_min3_f32 v92, |" A0 "|, |" A1 "|, v92\n v_min3_f32 v92, |" A2 "|, |" A3 "|, v92\n"               \
+  "v_sub_u32 v93, v48, v52\n v_and_b32 v93, " A0 ", v93\n v_alignbit_b32 v94, v94, v93, 31\n"        \
+  "v_sub_u32 v93, v49, v52\n v_and_b32 v93, " A1 ", v93\n v_alignbit_b32 v95, v95, v93, 31\n"        \
+  "v_sub_u32 v93, v50, v52\n v_and_b32 v93, " A2 ", v93\n v_alignbit_b32 v96, v96, v93, 31\n"        \
+  "v_sub_u32 v93, v51, v52\n v_and_b32 v93, " A3 ", v93\n v_alignbit_b32 v97, v97, v93, 31\n"        \
+  "v_cmp_gt_f32 vcc, s46, v92\n"
+#define TILE_CLOB "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v92", "v93", "v94", "v95", "v96", "v97", "vcc"
+    } else if (KIND == 26) {  // one tile step of k_sweep_mfma_f32: fp32 MFMA into one accumulator, 15 VALU on the other
+      REP8(asm volatile("v_mfma_f32_16x16x4_f32 v[60:63], v46, v47, v[56:59]\n" TILE_VALU("v64", "v65", "v66", "v67")
+                        "v_mfma_f32_16x16x4_f32 v[64:67], v46, v47, v[56:59]\n" TILE_VALU("v60", "v61", "v62", "v63") ::: TILE_CLOB);)
+    } else if (KIND == 27) {  // same with the f16 MFMA (K = 32)
+      REP8(asm volatile("v_mfma_f32_16x16x32_f16 v[60:63], v[40:43], v[44:47], v[56:59]\n" TILE_VALU("v64", "v65", "v66", "v67")
+                        "v_mfma_f32_16x16x32_f16 v[64:67], v[40:43], v[44:47], v[56:59]\n" TILE_VALU("v60", "v61", "v62", "v63") ::: TILE_CLOB);)
+    } else if (KIND == 28) {  // the 15 VALU of a tile step without any MFMA
+      REP8(asm volatile(TILE_VALU("v64", "v65", "v66", "v67") TILE_VALU("v60", "v61", "v62", "v63") ::: TILE_CLOB);)
     } else if (KIND == 13) {  // two tests per pass in packed form: 2 i-particles (SGPR pairs) against the same j
       // 8 packed + 4 compares for 2 tests = 6 instructions per test; fixed registers (timing only)
       REP8(asm volatile(
@@ -188,6 +235,18 @@ int main() {
   CHK(hipGetDeviceProperties(&prop, 0));
   printf("device %s, %d CUs. cycles = shader cycles (s_memtime) per wave-instruction per SIMD, median/max over waves\n",
          prop.gcnArchName, prop.multiProcessorCount);
+  if (getenv("MICRO_MFMA")) {  // the instruction mix of k_sweep_mfma_f32 only
+    run<22>("v_sub_u32", 64, out, stamps);
+    run<21>("v_and_b32", 64, out, stamps);
+    run<20>("v_alignbit_b32", 64, out, stamps);
+    run<23>("v_min3_f32 |a|,|b|,c", 64, out, stamps);
+    run<24>("v_mfma_f32_16x16x4_f32 (indep.)", 64, out, stamps);
+    run<25>("v_mfma_f32_16x16x32_f16 (indep.)", 64, out, stamps);
+    run<28>("tile step: 15 VALU only /step", 16, out, stamps);
+    run<26>("tile step: f32 MFMA + 15 VALU /step", 16, out, stamps);
+    run<27>("tile step: f16 MFMA + 15 VALU /step", 16, out, stamps);
+    return 0;
+  }
   run<0>("v_add_f32", 64, out, stamps);
   run<4>("v_fma_f32", 64, out, stamps);
   run<1>("v_pk_add_f32", 64, out, stamps);
