@@ -204,7 +204,9 @@ def main():
             # (16|32 B) + sorted_row (4 B) read, counts (4 B) and the list (4 B per half pair) written.
             info = nl.build_info()
             if info["masks"]:
-                kname, kms = ("k_sweep_count_masks_f32" if args.dtype == "f32" else "k_sweep<double,COUNT_MASKS>"), stages["count"]
+                kname = ("k_sweep_mfma_f32" if info["mfma"] else "k_sweep_count_masks_f32") if args.dtype == "f32" \
+                    else "k_sweep<double,COUNT_MASKS>"
+                kms = stages["count"]
             elif stages["fill"] >= stages["count"]:
                 kname, kms = "k_sweep<FILL>", stages["fill"]
             else:
@@ -215,7 +217,7 @@ def main():
                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                         "traffic": _traffic_from_profiles(kname) if world == 1 else None,
                         "algorithmic_bytes_per_launch": b_search, "kernel_ms": round(kms, 4),
-                        "note": "VALU-issue bound, not HBM bound: 10 VALU + 3 SALU per 64 distance tests (DESIGN.md "
+                        "note": "VALU-issue bound, not HBM bound: 12 VALU + 4 SALU per 64 distance tests (DESIGN.md "
                                 "section 4); `build` gives the whole-build HBM fraction",
                         "stages_ms": {k: round(v, 4) for k, v in stages.items()}}
         b_build = n_total * vec_bytes + 4 * npairs + 4 * (n_total + 1) + 4 * n_total

@@ -228,8 +228,8 @@ __global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f32(SweepArgs<
       src[q] = __builtin_amdgcn_readlane(c.seg_src, sg);
       off[q] = __builtin_amdgcn_readlane(c.seg_off, sg);
 #pragma unroll
-      for (int k = 0; k < NK; k++)
-        if (k * WAVE < len[q]) v[q][k] = a.sorted[src[q] + min(k * WAVE + lane, len[q] - 1)];
+      for (int k = 0; k < NK; k++)  // (unconditional: an empty segment re-reads one valid particle)
+        v[q][k] = a.sorted[src[q] + max(min(k * WAVE + lane, len[q] - 1), 0)];
     }
 #pragma unroll
     for (int q = 0; q < NS; q++) {

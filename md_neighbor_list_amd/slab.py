@@ -80,6 +80,8 @@ class SlabState:
 
 def _p2p(ops_spec, staging_cpu: bool):
     """ops_spec: list of ("send"|"recv", tensor, peer).  One grouped batch of point-to-point transfers."""
+    # An empty boundary layer sends nothing: both sides know the count (setup exchanged it), so both skip the message.
+    ops_spec = [(kind, t, peer) for kind, t, peer in ops_spec if t.numel() > 0]
     if not ops_spec:
         return
     bufs, ops = [], []

@@ -37,6 +37,8 @@ def test_z_layer_matches_oracle_hash():
     (2, (6000, (14.0, 14.0, 20.0), 3.3, "float32", 71)),   # 6 layers: 3 + 3
     (3, (9000, (13.5, 15.0, 30.0), 3.3, "float64", 72)),   # 9 layers: 3 + 3 + 3
     (2, (4000, (12.0, 12.0, 17.0), 3.3, "float32", 73)),   # 5 layers: 3 + 2
+    (2, (6000, (14.0, 14.0, 20.0), 3.3, "float32", 74, [2, 3])),  # layers 2 and 3 empty: zero-size ghost messages
+    (3, (9000, (13.5, 15.0, 30.0), 3.3, "float32", 75, [0, 5])),  # empty layers at a slab top and at the box bottom
 ])
 def test_slab_union_equals_global_list_cpu(world, case):
     res = run(world, "oracle", case)

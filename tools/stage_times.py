@@ -7,7 +7,10 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from md_neighbor_list_amd import NeighListGPU, inputs  # noqa: E402
+from md_neighbor_list_amd import NeighListGPU, inputs, _lib  # noqa: E402
+
+if os.environ.get("NL_LIB"):  # development only: A/B another build of the library in the same session
+    _lib.LIB_PATH = os.path.abspath(os.environ["NL_LIB"])
 
 CFGS = {
     "cfg2": (1 << 20, 1.0, 3.3, np.float32),
