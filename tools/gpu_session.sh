@@ -35,6 +35,7 @@ for s in $STEPS; do
     stages) run 300 "$OUT/stages.log" python tools/stage_times.py; cat "$OUT/stages.log" ;;
     sbench) run 120 "$OUT/search_bench.log" ./tools/search_bench; cat "$OUT/search_bench.log" ;;
     micro) run 120 "$OUT/microbench.log" ./tools/microbench; cat "$OUT/microbench.log" ;;
+    microtail) export MICRO_TAIL=1; run 120 "$OUT/microbench_tail.log" ./tools/microbench; cat "$OUT/microbench_tail.log" ;;
     micromf) export MICRO_MFMA=1; run 120 "$OUT/microbench_mfma.log" ./tools/microbench; cat "$OUT/microbench_mfma.log" ;;
     tests) run 900 "$OUT/pytest_gpu.log" python -m pytest tests -m gpu -q -x --durations=8; tail -25 "$OUT/pytest_gpu.log" ;;
     bench) run 420 "$OUT/bench.log" python bench.py --steps 50 --warmup 5; tail -3 "$OUT/bench.log" ;;

@@ -168,6 +168,22 @@ __global__ void __launch_bounds__(1024) k(float* out, unsigned long long* stamps
                         "v_mfma_f32_16x16x32_f16 v[64:67], v[40:43], v[44:47], v[56:59]\n" TILE_VALU("v60", "v61", "v62", "v63") ::: TILE_CLOB);)
     } else if (KIND == 28) {  // the 15 VALU of a tile step without any MFMA
       REP8(asm volatile(TILE_VALU("v64", "v65", "v66", "v67") TILE_VALU("v60", "v61", "v62", "v63") ::: TILE_CLOB);)
+    } else if (KIND == 30) {  // test with the sign-bit tail: sub(r2 - rc2'), sub_u32(id order), and, alignbit; no scalar ops
+      REP8(asm volatile(
+               "v_subrev_f32 v40, s40, v46\n v_subrev_f32 v41, s41, v47\n v_subrev_f32 v42, s42, v48\n"
+               "v_mul_f32 v40, v40, v40\n v_mul_f32 v41, v41, v41\n v_mul_f32 v42, v42, v42\n"
+               "v_add_f32 v40, v40, v41\n v_add_f32 v40, v40, v42\n"
+               "v_subrev_f32 v40, s46, v40\n v_sub_u32 v43, s47, v52\n v_and_b32 v40, v40, v43\n v_alignbit_b32 v44, v44, v40, 31\n"
+               ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53");)
+    } else if (KIND == 31) {  // the count-and-mask tail of k_sweep_count_masks_f32 today: 2 cmp, s_and, s_bcnt1, s_add, cndmask-or
+      REP8(asm volatile(
+               "v_subrev_f32 v40, s40, v46\n v_subrev_f32 v41, s41, v47\n v_subrev_f32 v42, s42, v48\n"
+               "v_mul_f32 v40, v40, v40\n v_mul_f32 v41, v41, v41\n v_mul_f32 v42, v42, v42\n"
+               "v_add_f32 v40, v40, v41\n v_add_f32 v40, v40, v42\n"
+               "v_cmp_lt_i32 s[52:53], s47, v52\n v_cmp_nlt_f32 vcc, s46, v40\n"
+               "s_and_b64 s[48:49], s[52:53], vcc\n v_or_b32 v43, 4, v44\n v_cndmask_b32 v44, v44, v43, s[48:49]\n"
+               "s_bcnt1_i32_b64 s50, s[48:49]\n s_add_i32 s51, s51, s50\n"
+               ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "s48", "s49", "s50", "s51", "s52", "s53", "vcc", "scc");)
     } else if (KIND == 13) {  // two tests per pass in packed form: 2 i-particles (SGPR pairs) against the same j
       // 8 packed + 4 compares for 2 tests = 6 instructions per test; fixed registers (timing only)
       REP8(asm volatile(
@@ -235,6 +251,13 @@ int main() {
   CHK(hipGetDeviceProperties(&prop, 0));
   printf("device %s, %d CUs. cycles = shader cycles (s_memtime) per wave-instruction per SIMD, median/max over waves\n",
          prop.gcnArchName, prop.multiProcessorCount);
+  if (getenv("MICRO_TAIL")) {  // which hit-recording tail for the VALU sweep
+    run<12>("test body unpacked (10 instr) /test", 8, out, stamps);
+    run<14>("test + s_and,s_bcnt1,s_add /test", 8, out, stamps);
+    run<31>("test + count + mask bits (today) /test", 8, out, stamps);
+    run<30>("test + sign-bit tail (12 VALU, 0 SALU) /test", 8, out, stamps);
+    return 0;
+  }
   if (getenv("MICRO_MFMA")) {  // the instruction mix of k_sweep_mfma_f32 only
     run<22>("v_sub_u32", 64, out, stamps);
     run<21>("v_and_b32", 64, out, stamps);

@@ -72,6 +72,6 @@ for name in sys.argv[1:] or ["cfg2", "cfg3"]:
     if flags & 4 and nl.build_info().get("mfma"):
         rec = buf[64:64 + 2048 * 8].reshape(2048, 8)[:, :6].astype(np.float64)
         rec = rec[rec.sum(axis=1) > 0]
-        names = ["cell table", "staging", "barrier", "search+deposit", "barrier", "stores+count"]
+        names = ["cell table", "staging", "barrier", "search+stores", "barrier", "counts"]
         print("   k_sweep_mfma_f32 thread-0 cycles per cell: " + "  ".join(f"{nm} {rec[:, i].mean():.0f}" for i, nm in enumerate(names))
               + f"  (total {rec.sum(axis=1).mean():.0f}, {len(rec)} records)")
