@@ -83,6 +83,26 @@ def _cpu_model():
     return "unknown"
 
 
+def _measured_copy_gbs(torch, dev):
+    """Device-to-device copy rate (read + write bytes per second) of this GPU right now: what the reference reports
+    next to its numbers as GPU_STREAM_RESULT.txt.  1 GiB buffers, best of 5."""
+    n = 1 << 28
+    a = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * 4.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return round(best, 1)
+
+
 def _traffic_from_profiles(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC passes (profiles/*_pmc.json), or None."""
     best = None
@@ -213,8 +233,10 @@ def main():
                 kname, kms = "k_sweep<COUNT>", stages["count"]
             b_search = n_loc * (vec_bytes + 8) + 4 * p_loc
             gbs = b_search / (kms * 1e-3) / 1e9
+            copy_gbs = _measured_copy_gbs(torch, dev)
             roofline = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": round(gbs / copy_gbs, 4),
                         "traffic": _traffic_from_profiles(kname) if world == 1 else None,
                         "algorithmic_bytes_per_launch": b_search, "kernel_ms": round(kms, 4),
                         "note": "VALU-issue bound, not HBM bound: 12 VALU + 4 SALU per 64 distance tests (DESIGN.md "

@@ -118,6 +118,8 @@ template <typename Vec, typename Dtype> class NeighListGPU {
  public:
   NeighListGPU(const Dtype search_length, const Dtype Lx, const Dtype Ly, const Dtype Lz) {  // neighlist_gpu.hpp:236-255
     NL_SHIM_CHECK(nl_create(&h_, std::is_same<Dtype, float>::value ? NL_F32 : NL_F64, search_length, Lx, Ly, Lz, -1));
+    // this class's contract is the FULL list (every j != i within the cut-off, kernel_impl.cuh:24-33)
+    NL_SHIM_CHECK(nl_set_list_kind(h_, NL_LIST_FULL));
   }
   ~NeighListGPU() {
     if (h_) (void)nl_destroy(h_);
@@ -128,6 +130,10 @@ template <typename Vec, typename Dtype> class NeighListGPU {
   NeighListGPU& operator=(NeighListGPU&&) = delete;
 
   void Initialize(const int32_t particle_number) { NL_SHIM_CHECK(nl_initialize(h_, particle_number)); }  // :268-287
+
+  // Extension: build the scalar CPU class's half list instead (key_pointer / sorted_list / half_number_of_partners
+  // below; neigh_list() is then derived from it with scattered writes, about ten times slower).
+  void UseHalfList(const bool half = true) { NL_SHIM_CHECK(nl_set_list_kind(h_, half ? NL_LIST_HALF : NL_LIST_FULL)); }
 
   // neighlist_gpu.hpp:289-293.  tblock_size / smem_hei chose among the reference's CUDA variants; ignored.
   void MakeNeighList(cuda_ptr<Vec>& q, const int32_t particle_number, const bool sync = true, int32_t tblock_size = 128,
@@ -153,7 +159,7 @@ template <typename Vec, typename Dtype> class NeighListGPU {
     return static_cast<int32_t>(2 * p);
   }
 
-  // --- the scalar CPU class's outputs (neighlist_cpu.hpp:437-463), device-resident
+  // --- the scalar CPU class's outputs (neighlist_cpu.hpp:437-463), device-resident; after UseHalfList()
   int64_t half_number_of_pairs() const {
     int64_t p = 0;
     NL_SHIM_CHECK(nl_number_of_pairs(h_, &p));

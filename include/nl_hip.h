@@ -74,6 +74,15 @@ int nl_initialize(nl_handle_t h, int32_t n_max);
  * one (sync = 0) cannot, and reports NL_ERR_CAPACITY at the next synchronising call instead of overrunning. */
 int nl_set_capacity(nl_handle_t h, int64_t max_pairs);
 
+/* Which list the builds of this handle produce.  NL_LIST_HALF (default): the scalar CPU class's contract, every
+ * pair once, in the row of min(i, j) (neighlist_cpu.hpp:233-236).  NL_LIST_FULL: the GPU kernels' contract, every
+ * pair in both rows (kernel_impl.cuh:24-33: every j != i within the cut-off), as a CSR in original particle order;
+ * nl_get_full_transposed then turns it into the GPU class's list[k*N + i] with coalesced writes instead of
+ * deriving it from the half list.  Takes effect at the next build; the list capacity is counted in entries
+ * (a full list has twice as many) and is re-estimated unless it was set by nl_set_capacity. */
+enum nl_list_kind { NL_LIST_HALF = 0, NL_LIST_FULL = 1 };
+int nl_set_list_kind(nl_handle_t h, int kind);
+
 int nl_destroy(nl_handle_t h);
 
 /* --------------------------------------------------------------------------------------------------- build */
@@ -113,10 +122,17 @@ int nl_synchronize(nl_handle_t h);
 int nl_get_half_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_t** sorted_list_dev,
                     const int32_t** number_of_partners_dev, int64_t* npairs);
 
+/* The same arrays of a NL_LIST_FULL build: key_pointer[N+1], list[2P], full counts [N]; *nentries = 2P.
+ * NL_ERR_STATE if the last build was a half build (and nl_get_half_csr after a full build). */
+int nl_get_full_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_t** list_dev,
+                    const int32_t** number_of_partners_dev, int64_t* nentries);
+
 /* The GPU class's accessors neigh_list() / number_of_partners() (neighlist_gpu.hpp:468-482): the FULL list in
- * the transposed layout list[k * row_stride + i], k < count[i], original particle ids, derived on the device
- * from the half list of the last build.  Rows k >= count[i] hold -1 (the reference fills -1 once in Initialize,
- * neighlist_gpu.hpp:271).  *max_partners receives the number of rows written (max_i count[i]).  Synchronises. */
+ * the transposed layout list[k * row_stride + i], k < count[i], original particle ids: converted from the full
+ * CSR of a NL_LIST_FULL build (one coalesced pass), or derived on the device from the half list of a NL_LIST_HALF
+ * build (scattered writes: about ten times slower).  Entries k >= count[i] hold -1 when the buffer is first
+ * allocated or grown and whatever an earlier build left there afterwards (the reference fills -1 once in
+ * Initialize and never again, neighlist_gpu.hpp:271).  *max_partners receives max_i count[i].  Synchronises. */
 int nl_get_full_transposed(nl_handle_t h, const int32_t** list_dev, const int32_t** count_dev, int64_t* row_stride,
                            int32_t* max_partners);
 

@@ -21,11 +21,13 @@ PROTOTYPES = {
     "nl_create": (C.c_int, [C.POINTER(_P), C.c_int, _D, _D, _D, _D, C.c_int]),
     "nl_initialize": (C.c_int, [_P, _I32]),
     "nl_set_capacity": (C.c_int, [_P, _I64]),
+    "nl_set_list_kind": (C.c_int, [_P, C.c_int]),
     "nl_destroy": (C.c_int, [_P]),
     "nl_make_list": (C.c_int, [_P, _P, _I32, _I32, _P, C.c_int]),
     "nl_make_list_slab": (C.c_int, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, C.c_int]),
     "nl_synchronize": (C.c_int, [_P]),
     "nl_get_half_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
+    "nl_get_full_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "nl_get_full_transposed": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.POINTER(_I32)]),
     "nl_number_of_pairs": (C.c_int, [_P, C.POINTER(_I64)]),
     "nl_get_mesh": (C.c_int, [_P, C.POINTER(_I32 * 3), C.POINTER(_I64)]),

@@ -42,8 +42,9 @@ struct nl_handle_s {
   float mfma_delta = 0;  // k_sweep_mfma_f32: half-width of the band that is re-tested exactly (mfma_delta())
 
   int32_t n_max = 0;
-  int64_t capacity = 0;
+  int64_t capacity = 0;      // list entries (half pairs, or twice as many for a full list)
   bool capacity_user = false;
+  int list_kind = NL_LIST_HALF;
 
   // device buffers
   int32_t* rank = nullptr;
@@ -96,6 +97,8 @@ struct nl_handle_s {
   int32_t b_mzl = 0, b_slab = 0, b_zlo = 0, b_stride = 4;
   bool b_use_masks = false;  // this build: COUNT keeps hit masks and the list is expanded from them
   bool b_use_mfma = false;   // ... and the masks come from k_sweep_mfma_f32 (layout MASK_TILE16)
+  bool b_full = false;       // this build: full list (both directions), nl_set_list_kind
+  int b_variant = 3;         // sweep variant of this build (a full build uses 1 or 3 only)
   const void* b_q = nullptr;
   const int32_t* b_gid = nullptr;
 };
@@ -210,12 +213,14 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   return a;
 }
 
-template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) {
+// FULL = the list keeps both directions of every pair (the reference GPU class's contract); the persistent and
+// matrix-core variants exist for the half list only and are not selected for a full build (enqueue_build).
+template <typename T, bool FULL> void launch_sweep_kind(nl_handle_t h, int mode, hipStream_t s) {
   const int32_t owned_layers = h->b_slab ? h->b_mzl - 2 : h->b_mzl;
   const int32_t ncells_i = h->m[0] * h->m[1] * owned_layers;
   const SweepArgs<T> a = sweep_args<T>(h);
-  if constexpr (sizeof(T) == 4) {
-    if (h->sweep_variant == 2) {
+  if constexpr (sizeof(T) == 4 && !FULL) {
+    if (h->b_variant == 2) {
       // persistent kernel: 4 workgroups of 8 waves per CU (2 x 20 KiB LDS each), each walking a run of cells
       const int32_t grid = std::max(8, std::min(h->dbg_wg_per_cu * h->num_cus, (ncells_i + 1) / 2 / 8 * 8));
       if (mode == MODE_COUNT) {
@@ -235,31 +240,46 @@ template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) 
   if (h->b_use_masks) {
     if (mode == MODE_COUNT) {
       if constexpr (sizeof(T) == 4) {
-        if (h->b_use_mfma)
-          hipLaunchKernelGGL(k_sweep_mfma_f32, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
-        else
-          hipLaunchKernelGGL(k_sweep_count_masks_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+        if constexpr (!FULL) {
+          if (h->b_use_mfma) {
+            hipLaunchKernelGGL(k_sweep_mfma_f32, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
+            return;
+          }
+        }
+        hipLaunchKernelGGL(k_sweep_count_masks_f32<FULL>, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
       } else
-        hipLaunchKernelGGL((k_sweep<T, MODE_COUNT_MASKS>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+        hipLaunchKernelGGL((k_sweep<T, MODE_COUNT_MASKS, FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
     } else {
       const int32_t nbp = (h->n + 255) / 256;
       if (h->n > 0)
         hipLaunchKernelGGL(k_row_base, dim3(nbp), dim3(256), 0, s, h->key_pointer, h->sorted_row, h->n_rows, h->n,
                            h->base_sorted);
-      if (h->b_use_mfma)
-        hipLaunchKernelGGL((k_fill_masks<T, MASK_TILE16>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
-      else
-        hipLaunchKernelGGL((k_fill_masks<T, MASK_LANE64>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
+      if constexpr (!FULL) {
+        if (h->b_use_mfma) {
+          hipLaunchKernelGGL((k_fill_masks<T, MASK_TILE16>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
+                             h->base_sorted);
+          return;
+        }
+      }
+      hipLaunchKernelGGL((k_fill_masks<T, MASK_LANE64, FULL>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
+                         h->base_sorted);
     }
     return;
   }
   if (mode == MODE_COUNT) {
     if constexpr (sizeof(T) == 4)
-      hipLaunchKernelGGL(k_sweep_count_f32, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+      hipLaunchKernelGGL(k_sweep_count_f32<FULL>, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
     else
-      hipLaunchKernelGGL((k_sweep<T, MODE_COUNT>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+      hipLaunchKernelGGL((k_sweep<T, MODE_COUNT, FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
   } else
-    hipLaunchKernelGGL((k_sweep<T, MODE_FILL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+    hipLaunchKernelGGL((k_sweep<T, MODE_FILL, FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+}
+
+template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) {
+  if (h->b_full)
+    launch_sweep_kind<T, true>(h, mode, s);
+  else
+    launch_sweep_kind<T, false>(h, mode, s);
 }
 
 // Enqueues one whole build. ev != nullptr: records an event before every stage and one after the last.
@@ -272,8 +292,10 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   h->b_mzl = mzl, h->b_slab = slab, h->b_zlo = z_lo, h->b_stride = stride, h->b_q = q_dev, h->b_gid = gid;
   // Hit masks pay off while a cell's stencil fits one LDS batch; where the mean stencil (27 cells) is close to or
   // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
-  h->b_use_masks = h->sweep_variant >= 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
-  h->b_use_mfma = h->b_use_masks && h->sweep_variant == 4 && sizeof(T) == 4;
+  h->b_full = h->list_kind == NL_LIST_FULL;
+  h->b_variant = h->b_full ? (h->sweep_variant >= 3 ? 3 : 1) : h->sweep_variant;
+  h->b_use_masks = h->b_variant >= 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
+  h->b_use_mfma = h->b_use_masks && h->b_variant == 4 && sizeof(T) == 4;
   const int32_t nbp = (n + 255) / 256;
   const T* q = static_cast<const T*>(q_dev);
 
@@ -328,6 +350,21 @@ int dispatch_build(nl_handle_t h, const void* q, int32_t stride, const int32_t* 
                    int32_t z_lo, int32_t mzl, int32_t slab, hipStream_t s, hipEvent_t* ev) {
   return h->dtype == NL_F32 ? enqueue_build<float>(h, q, stride, gid, n_rows, n, z_lo, mzl, slab, s, ev)
                             : enqueue_build<double>(h, q, stride, gid, n_rows, n, z_lo, mzl, slab, s, ev);
+}
+
+// Default list capacity (unless the caller fixed it): ideal-gas estimate of the half-pair count
+// N * rho * (2/3) pi rc^3 with 30 % head room, twice that for a full list.
+int estimate_capacity(nl_handle_t h) {
+  if (h->capacity_user) return NL_OK;
+  const double rho = (double)h->n_max / (h->L[0] * h->L[1] * h->L[2]);
+  const double per = rho * (2.0 / 3.0) * 3.14159265358979323846 * h->rc * h->rc * h->rc;
+  int64_t want = (int64_t)((double)h->n_max * per * 1.3) + 64 * (int64_t)h->n_max + 4096;
+  if (h->list_kind == NL_LIST_FULL) want *= 2;
+  if (want > h->capacity) {
+    if (int rc = dev_alloc(h, &h->list, 4 * (size_t)want)) return rc;
+    h->capacity = want;
+  }
+  return NL_OK;
 }
 
 int grow_list(nl_handle_t h, int64_t need) {
@@ -524,17 +561,23 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   HIPCHK(h, hipMemset(h->totals, 0, 32));
   HIPCHK(h, hipMemset(h->cell_count, 0, 4 * ((size_t)h->ncell + 64 + (size_t)h->m[1] * h->m[2])));
   h->n_max = n_max;
-  if (!h->capacity_user) {
-    // ideal-gas estimate of the half-pair count: N * rho * (2/3) pi rc^3, with 30 % head room
-    const double rho = (double)n_max / (h->L[0] * h->L[1] * h->L[2]);
-    const double per = rho * (2.0 / 3.0) * 3.14159265358979323846 * h->rc * h->rc * h->rc;
-    const int64_t want = (int64_t)((double)n_max * per * 1.3) + 64 * (int64_t)n_max + 4096;
-    if (want > h->capacity) {
-      if ((rc = dev_alloc(h, &h->list, 4 * (size_t)want))) return rc;
-      h->capacity = want;
-    }
-  }
+  if ((rc = estimate_capacity(h))) return rc;
   h->t_valid = false;
+  return NL_OK;
+}
+
+int nl_set_list_kind(nl_handle_t h, int kind) {
+  if (!h || (kind != NL_LIST_HALF && kind != NL_LIST_FULL)) return fail(h, NL_ERR_ARG);
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->pending) (void)finish(h, false);
+  if (kind != h->list_kind) {
+    h->list_kind = kind;
+    h->built = false;
+    h->t_valid = false;
+    h->t_rows_cap = 0;  // the transposed buffer is re-allocated (and -1 filled) for the other kind
+    if (h->n_max > 0)
+      if (int rc = estimate_capacity(h)) return rc;
+  }
   return NL_OK;
 }
 
@@ -603,11 +646,25 @@ int nl_synchronize(nl_handle_t h) {
   return finish(h, false);
 }
 
+int nl_get_full_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_t** list_dev,
+                    const int32_t** number_of_partners_dev, int64_t* nentries) {
+  if (!h) return NL_ERR_ARG;
+  int rc = nl_synchronize(h);
+  if (rc) return rc;
+  if (!h->b_full) return fail(h, NL_ERR_STATE);
+  if (key_pointer_dev) *key_pointer_dev = h->key_pointer;
+  if (list_dev) *list_dev = h->list;
+  if (number_of_partners_dev) *number_of_partners_dev = h->count;
+  if (nentries) *nentries = h->host->total();
+  return NL_OK;
+}
+
 int nl_get_half_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_t** sorted_list_dev,
                     const int32_t** number_of_partners_dev, int64_t* npairs) {
   if (!h) return NL_ERR_ARG;
   int rc = nl_synchronize(h);
   if (rc) return rc;
+  if (h->b_full) return fail(h, NL_ERR_STATE);
   if (key_pointer_dev) *key_pointer_dev = h->key_pointer;
   if (sorted_list_dev) *sorted_list_dev = h->list;
   if (number_of_partners_dev) *number_of_partners_dev = h->count;
@@ -619,7 +676,7 @@ int nl_number_of_pairs(nl_handle_t h, int64_t* npairs) {
   if (!h || !npairs) return fail(h, NL_ERR_ARG);
   int rc = nl_synchronize(h);
   if (rc) return rc;
-  *npairs = h->host->total();
+  *npairs = h->b_full ? h->host->total() / 2 : h->host->total();
   return NL_OK;
 }
 
@@ -662,7 +719,7 @@ int nl_debug_occupancy(int32_t out[8]) {
   out[2] = v;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_p<float, MODE_FILL>, PW * WAVE, 0);
   out[3] = v;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_count_f32, SWEEP_WAVES * WAVE, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_count_f32<false>, SWEEP_WAVES * WAVE, 0);
   out[4] = v;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep<float, MODE_FILL>, SWEEP_WAVES * WAVE, 0);
   out[5] = v;

@@ -519,7 +519,7 @@ constexpr int NSEG = 18;
 // particle t*64 + l is accepted (2 VALU per test, no scalar work); the 64 words of an i-particle go to
 // a.masks[(slot0 + k) * 64 + l] at the end (store_masks: only for cells whose stencil fits one LDS batch, which
 // also bounds t by CAP/64 <= 32).
-template <typename T, int MODE, int GC>
+template <typename T, int MODE, int GC, bool FULL = false>
 __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos<T>* tile, int32_t nj,
                                                 int32_t ntiles, int lane, const Pos<T>& pi_l, int32_t base_l,
                                                 int32_t slot0 = 0, bool store_masks = false) {
@@ -555,7 +555,8 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
     for (int k = 0; k < GC; k++) {
       const T dx = sub_rn(pj.x, xi[k]), dy = sub_rn(pj.y, yi[k]), dz = sub_rn(pj.z, zi[k]);
       const T r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-      const bool in_range = !(r2 > a.rc2), upper = pj.gid > gi[k];
+      // half list: j is kept by the particle with the smaller id; full list: everyone but i itself
+      const bool in_range = !(r2 > a.rc2), upper = FULL ? pj.gid != gi[k] : pj.gid > gi[k];
       hit[k] = in_range && upper;
       mask[k] = __builtin_amdgcn_ballot_w64(in_range) & __builtin_amdgcn_ballot_w64(upper);
     }
@@ -577,7 +578,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   };
 
   // The staged stream is padded to a whole tile with sentinels (gid = INT32_MIN can never satisfy
-  // gid_j > gid_i), so tiles need no per-lane tail handling.  Two register sets in ping-pong: the ds_read of the
+  // gid_j > gid_i, and their position 1e18 is never in range), so tiles need no per-lane tail handling.  Two register sets in ping-pong: the ds_read of the
   // next tile is in flight while the current one is tested, and no register copies are needed.
   const int32_t last = (ntiles - 1) * WAVE + lane;
   Pos<T> pa = tile[lane], pb;
@@ -656,7 +657,7 @@ template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs
 }
 
 // The pair search of one cell: stage the stencil stream into `tile` (in batches of CAP), search it group by group.
-template <typename T, int MODE, int CAP = SweepCfg<T>::CAP, int NW = SWEEP_WAVES>
+template <typename T, int MODE, int CAP = SweepCfg<T>::CAP, int NW = SWEEP_WAVES, bool FULL = false>
 __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx& c, Pos<T>* tile, int tid, int lane,
                                             int wave) {
   constexpr int G = SWEEP_G;
@@ -694,7 +695,8 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       const int32_t pad = nj + tid;
       if (pad < ((nj + WAVE - 1) & ~(WAVE - 1))) {
         Pos<T> sentinel;
-        sentinel.x = 0, sentinel.y = 0, sentinel.z = 0, sentinel.gid = INT32_MIN;
+        // far outside any box (r2 ~ 1e36 / 1e300, finite: never in range) AND an id that is never the upper one
+        sentinel.x = sizeof(T) == 4 ? (T)1.0e18f : (T)1.0e150, sentinel.y = 0, sentinel.z = 0, sentinel.gid = INT32_MIN;
         if constexpr (sizeof(T) == 8) sentinel.row = 0;
         tile[pad] = sentinel;
       }
@@ -722,11 +724,11 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       const bool keep = nbatch == 1 && CAP == SweepCfg<T>::CAP;
       int32_t mine;  // lane k < gcount: hits of i-particle k in this batch
       switch (gcount) {
-        case 1: mine = search_group<T, MODE, 1>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        case 2: mine = search_group<T, MODE, 2>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        case 3: mine = search_group<T, MODE, 3>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        case 4: mine = search_group<T, MODE, 4>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        default: mine = search_group<T, MODE, 5>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        case 1: mine = search_group<T, MODE, 1, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        case 2: mine = search_group<T, MODE, 2, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        case 3: mine = search_group<T, MODE, 3, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        case 4: mine = search_group<T, MODE, 4, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        default: mine = search_group<T, MODE, 5, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
       }
       if (lane < gcount) {
         if (nbatch > 1) {
@@ -740,7 +742,7 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
   }
 }
 
-template <typename T, int MODE> __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
+template <typename T, int MODE, bool FULL = false> __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   __shared__ Pos<T> tile[SweepCfg<T>::CAP];
   if (MODE == MODE_FILL) {
     if (a.total[0] > a.capacity) {  // uniform: every workgroup leaves, nothing is written out of bounds
@@ -751,22 +753,25 @@ template <typename T, int MODE> __device__ __forceinline__ void sweep_cell(const
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   CellCtx c;
   if (!cell_setup(a, lane, c)) return;
-  cell_search<T, MODE>(a, c, tile, tid, lane, wave);
+  cell_search<T, MODE, SweepCfg<T>::CAP, SWEEP_WAVES, FULL>(a, c, tile, tid, lane, wave);
 }
 
-template <typename T, int MODE> __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
-  sweep_cell<T, MODE>(a);
+template <typename T, int MODE, bool FULL = false>
+__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
+  sweep_cell<T, MODE, FULL>(a);
 }
 // The fp32 COUNT passes are held to 80 SGPRs: the SGPR file admits 8 waves per SIMD only up to 80 per wave (6 at
 // the 102 the compiler takes by itself).  FILL needs the extra SGPRs (cursors + masks): capped, it spills into its
 // inner loop and loses more than the occupancy gains.
+template <bool FULL = false>
 __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_sweep_count_f32(SweepArgs<float> a) {
-  sweep_cell<float, MODE_COUNT>(a);
+  sweep_cell<float, MODE_COUNT, FULL>(a);
 }
+template <bool FULL = false>
 __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_sweep_count_masks_f32(SweepArgs<float> a) {
-  sweep_cell<float, MODE_COUNT_MASKS>(a);
+  sweep_cell<float, MODE_COUNT_MASKS, FULL>(a);
 }
 
 // ------------------------------------------------------------------------------------------ list from masks
@@ -796,7 +801,7 @@ enum { MASK_LANE64 = 0, MASK_TILE16 = 1 };
 constexpr int MASK16_WORDS = 48;
 constexpr int MASK16_MAX_ROWS = 64;  // cells with more rows have no masks on the TILE16 path (searched again by k_fill_masks)
 
-template <typename T, int LAYOUT>
+template <typename T, int LAYOUT, bool FULL = false>
 __global__ void __launch_bounds__(EXPAND_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
@@ -820,7 +825,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
     // No masks for this cell (its stencil needed several LDS batches in COUNT_MASKS): search it again, as
     // k_sweep<FILL> does, in small batches through the id buffer.  Rare (very dense cells only).
     constexpr int CAPS = (int)(CAP * sizeof(int32_t) / (sizeof(Pos<T>))) / WAVE * WAVE;
-    cell_search<T, MODE_FILL, CAPS, EW>(a, c, reinterpret_cast<Pos<T>*>(gids), tid, lane, wave);
+    cell_search<T, MODE_FILL, CAPS, EW, FULL>(a, c, reinterpret_cast<Pos<T>*>(gids), tid, lane, wave);
     return;
   }
 

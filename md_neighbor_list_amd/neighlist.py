@@ -48,7 +48,7 @@ class NeighListGPU:
     plays the role of the reference's compile-time ``Dtype``/``Vec`` choice (make_list.cu:6-12).
     """
 
-    def __init__(self, search_length, Lx, Ly, Lz, dtype=torch.float32, device=None):
+    def __init__(self, search_length, Lx, Ly, Lz, dtype=torch.float32, device=None, full_list=False):
         if dtype not in (torch.float32, torch.float64):
             raise TypeError("dtype must be torch.float32 or torch.float64")
         self._lib = _lib.load()  # raises when the HIP extension is missing
@@ -69,6 +69,9 @@ class NeighListGPU:
         self.number_of_mesh = int(ncell.value)
         self._n = 0
         self._n_rows = 0
+        self.full_list = False
+        if full_list:
+            self.set_full_list(True)
         self._q = None  # keeps the positions of an asynchronous build alive
 
     def __del__(self):
@@ -86,6 +89,13 @@ class NeighListGPU:
 
     def set_capacity(self, max_pairs):
         check(self._lib.nl_set_capacity(self._h, int(max_pairs)), "nl_set_capacity")
+
+    def set_full_list(self, full=True):
+        """Builds produce the FULL list (every pair in both rows: the reference GPU kernels' contract,
+        kernel_impl.cuh:24-33) instead of the scalar CPU class's half list; ``neigh_list()`` is then one coalesced
+        conversion pass away.  The half-list accessors raise after a full build and vice versa."""
+        check(self._lib.nl_set_list_kind(self._h, 1 if full else 0), "nl_set_list_kind")
+        self.full_list = bool(full)
 
     def _check_q(self, q, n):
         if not isinstance(q, torch.Tensor) or q.device.type != "cuda":
@@ -159,6 +169,18 @@ class NeighListGPU:
         check(self._lib.nl_get_half_csr(self._h, C.byref(kp), C.byref(sl), C.byref(nop), C.byref(npairs)),
               "nl_get_half_csr")
         return kp.value, sl.value, nop.value, int(npairs.value)
+
+    def _full(self):
+        kp, sl, nop, ne = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(self._lib.nl_get_full_csr(self._h, C.byref(kp), C.byref(sl), C.byref(nop), C.byref(ne)), "nl_get_full_csr")
+        return kp.value, sl.value, nop.value, int(ne.value)
+
+    def full_csr(self):
+        """(key_pointer[N+1], list[2P], counts[N]) of a full-list build, as views valid until the next build."""
+        kp, sl, nop, ne = self._full()
+        return (_as_tensor(kp, (self._n_rows + 1,), "<i4", self, self.device),
+                _as_tensor(sl, (ne,), "<i4", self, self.device),
+                _as_tensor(nop, (self._n_rows,), "<i4", self, self.device))
 
     def half_number_of_pairs(self):
         """neighlist_cpu.hpp:437-439."""

@@ -246,3 +246,55 @@ def test_pairs_at_the_cutoff_fp32(variant, monkeypatch):
     assert int(kp[-1]) == ref.npairs
     assert np.array_equal(nop, ref.number_of_partners)
     assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+
+
+def _full_from_half(h):
+    """Symmetrised oracle list: (key_pointer, canonical list, counts) of the FULL neighbour list."""
+    n = len(h.key_pointer) - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(h.key_pointer))
+    cols = h.sorted_list.astype(np.int64)
+    a = np.concatenate([rows, cols])
+    b = np.concatenate([cols, rows])
+    order = np.lexsort((b, a))
+    cnt = np.bincount(a, minlength=n)
+    kp = np.concatenate([[0], np.cumsum(cnt)])
+    return kp, b[order].astype(np.int32), cnt.astype(np.int32)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("case", [
+    (50000, (36.84, 36.84, 36.84), 3.3, 51),  # hit-mask path
+    (9000, (25.0, 14.0, 19.0), 3.1, 52),      # non-cubic
+    (40000, (20.0, 20.0, 20.0), 3.3, 53),     # rho 5: two full sweeps / multi-batch re-search
+])
+def test_full_list_matches_the_symmetrised_oracle(case, dtype):
+    """NL_LIST_FULL (the reference GPU kernels' contract: every j != i within the cut-off, kernel_impl.cuh:24-33):
+    the full CSR, and the transposed list[k*N + i] converted from it, against the oracle's half list mirrored."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    n, box, rc, seed = case
+    q, box = inputs.uniform_box(n, dtype=dtype, seed=seed, box=box)
+    want_kp, want_list, want_cnt = _full_from_half(_po().build(q, rc, box))
+    nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64, full_list=True)
+    nl.Initialize(n)
+    nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+    kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr())
+    assert nl.number_of_pairs() == int(want_kp[-1]) and nl.half_number_of_pairs() * 2 == int(want_kp[-1])
+    assert np.array_equal(cnt, want_cnt)
+    assert np.array_equal(kp.astype(np.int64), want_kp)
+    assert np.array_equal(canonical_csr(kp, lst), want_list)
+    with pytest.raises(Exception):
+        nl.key_pointer()  # half accessors refuse a full build
+    # the GPU class's layout, converted from the full CSR
+    t = nl.neigh_list().cpu().numpy()
+    tc = nl.number_of_partners().cpu().numpy()
+    assert np.array_equal(tc, want_cnt)
+    for i in list(range(0, n, max(1, n // 997))) + [n - 1]:
+        assert np.array_equal(np.sort(t[: tc[i], i]), want_list[want_kp[i]:want_kp[i + 1]])
+    # and back to the half list on the same handle
+    nl.set_full_list(False)
+    nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+    assert nl.half_number_of_pairs() * 2 == int(want_kp[-1])
+    assert int(nl.key_pointer()[-1]) * 2 == int(want_kp[-1])
