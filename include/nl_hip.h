@@ -90,8 +90,10 @@ int nl_destroy(nl_handle_t h);
 /* Replaces MakeNeighList(q, N, sync, tblock_size, smem_hei) (neighlist_gpu.hpp:289-466) and MakeNeighList(q, N)
  * (neighlist_cpu.hpp:417-435).  q_dev: device pointer to n positions, `q_stride` scalars apart (4 for the
  * float4/double4 Vec of make_list.cu, 3 for the {x,y,z} Vec of make_list.cpp:26-32).  Positions are read, never
- * reordered (the reference's SortPtclData is commented out, neighlist_cpu.hpp:421).  stream: a hipStream_t or
- * NULL for the handle's own stream.  sync != 0 waits for the build and returns its status; sync == 0 only
+ * reordered (the reference's SortPtclData is commented out, neighlist_cpu.hpp:421).  stream: the hipStream_t the
+ * build is enqueued on; NULL is HIP's null (default) stream, where the reference launches (make_list.cu:124-127).
+ * The build is ordered after everything already queued on that stream (the kernel that produced q, a halo
+ * exchange) and nothing else: positions written on ANOTHER stream must be fenced by the caller.  sync != 0 waits for the build and returns its status; sync == 0 only
  * enqueues (the reference's timing loop, make_list.cu:124-127) and errors surface at the next nl_synchronize /
  * getter.  tblock_size and smem_hei of the reference select among its CUDA variants and have no counterpart. */
 int nl_make_list(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_t n, void* stream, int sync);

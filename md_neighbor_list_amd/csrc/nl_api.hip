@@ -617,10 +617,13 @@ int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const 
   if (h->pending) {
     // back-to-back asynchronous builds (the reference's timing loop): errors of the previous one are dropped,
     // exactly like its results; stream order keeps the buffers consistent when the stream is the same.
-    if (h->last_stream != (stream ? (hipStream_t)stream : h->own_stream)) HIPCHK(h, hipStreamSynchronize(h->last_stream));
+    if (h->last_stream != (hipStream_t)stream) HIPCHK(h, hipStreamSynchronize(h->last_stream));
     h->pending = false;
   }
-  hipStream_t s = stream ? (hipStream_t)stream : h->own_stream;
+  // The build runs on exactly the stream it is given; NULL is HIP's null (default) stream, as in the reference
+  // (make_list.cu:124-127 launches on the default stream), NOT a private stream: work the caller has queued on that
+  // stream before the call -- e.g. the kernel that wrote the positions, or a halo exchange -- is finished first.
+  hipStream_t s = (hipStream_t)stream;
   h->built = false;
   h->t_valid = false;
   h->n = n, h->n_rows = n_rows;
@@ -774,6 +777,8 @@ int nl_profile_last_build(nl_handle_t h, int32_t reps, double ms[NL_NUM_STAGES])
 int nl_profile_stages(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_t n, int32_t reps,
                       double ms[NL_NUM_STAGES]) {
   if (!h || !ms || reps <= 0) return fail(h, NL_ERR_ARG);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());  // diagnostic entry point: whatever produced q, on whichever stream, is done
   int rc = nl_make_list(h, q_dev, q_stride, n, nullptr, 1);
   if (rc) return rc;
   return nl_profile_last_build(h, reps, ms);

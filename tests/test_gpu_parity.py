@@ -298,3 +298,27 @@ def test_full_list_matches_the_symmetrised_oracle(case, dtype):
     nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
     assert nl.half_number_of_pairs() * 2 == int(want_kp[-1])
     assert int(nl.key_pointer()[-1]) * 2 == int(want_kp[-1])
+
+
+def test_build_is_ordered_after_pending_work_on_the_callers_stream():
+    """The positions are produced by a kernel queued on the caller's stream (here torch's default stream = HIP's null
+    stream) immediately before the build: the build must run after it.  (A private non-blocking stream for
+    stream == NULL read half-written positions at N = 1M: regression.)"""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    with open(os.path.join(GOLDEN, "known_answers.json")) as f:
+        known = json.load(f)
+    want = int(known["u1M_rho1_f32"]["npairs"])
+    q, box = inputs.uniform_box(1 << 20, 1.0, np.float32)
+    nl = NeighListGPU(3.3, *box, dtype=torch.float32)
+    nl.Initialize(len(q))
+    qd = torch.from_numpy(q).cuda()
+    perm = torch.randperm(len(q), device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        qp = qd[perm].contiguous()           # gather kernel, asynchronous
+        nl.MakeNeighList(qp, len(q))         # must wait for it
+        assert nl.half_number_of_pairs() == want
+        perm = perm.flip(0)
