@@ -8,7 +8,9 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 summ = json.load(open(f"{src}/pmc_summary.json"))
 names = {"k_sweep_count_masks_f32": "k_sweep_count_masks_f32", "k_sweep_count_f32": "k_sweep<COUNT>",
-         "k_sweep<float, 1>": "k_sweep<FILL>", "k_fill_masks<float>": "k_fill_masks<float>",
+         "k_sweep_mfma_f32": "k_sweep_mfma_f32", "k_sweep<float, 1": "k_sweep<FILL>",
+         "k_fill_masks<float": "k_fill_masks<float>", "k_bin_rows<float>": "k_bin_rows<float>",
+         "k_bin_scatter<float>": "k_bin_scatter<float>", "k_bin_cells<float>": "k_bin_cells<float>",
          "k_hash<float>": "k_hash<float>", "k_reorder<float>": "k_reorder<float>", "k_row_base": "k_row_base"}
 hbm, counters = {}, {}
 for k, e in summ.items():
