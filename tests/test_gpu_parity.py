@@ -322,3 +322,64 @@ def test_build_is_ordered_after_pending_work_on_the_callers_stream():
         nl.MakeNeighList(qp, len(q))         # must wait for it
         assert nl.half_number_of_pairs() == want
         perm = perm.flip(0)
+
+
+def test_random_small_boxes_against_oracle():
+    """Sixty seeded random problems: N from 1 to 6000, non-cubic boxes of 3..12 cells per axis, cut-offs from 0.5 to
+    5, both dtypes, half and full list; a tenth of the particles snapped onto cell faces / box faces, a few exact
+    duplicates.  Everything bit-exact against the oracle."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    rng = np.random.default_rng(20261003)
+    for case in range(60):
+        dtype = np.float32 if case % 2 == 0 else np.float64
+        rc = float(rng.uniform(0.5, 5.0))
+        mesh = rng.integers(3, 13, size=3)
+        box = tuple(float(m * rc * rng.uniform(1.0, 1.3)) for m in mesh)
+        n = int(rng.integers(1, 6001))
+        q = np.zeros((n, 4), dtype=dtype)
+        q[:, :3] = rng.uniform(0.0, 1.0, size=(n, 3)) * np.array(box)
+        snap = rng.random(n) < 0.1
+        ms = np.array([b / int(b / rc) for b in box])
+        q[snap, :3] = np.round(q[snap, :3] / ms) * ms  # onto cell faces (incl. 0 and L)
+        q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=dtype), dtype(0)))
+        if n > 10:
+            q[-3:] = q[:3]  # exact duplicates: distinct ids at distance 0
+        ref = _po().build(q, rc, box)
+        nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64,
+                          full_list=(case % 3 == 2))
+        nl.Initialize(n)
+        nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+        if case % 3 == 2:
+            kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr())
+            want_kp, want_list, want_cnt = _full_from_half(ref)
+            assert np.array_equal(kp.astype(np.int64), want_kp), case
+            assert np.array_equal(canonical_csr(kp, lst), want_list), case
+        else:
+            kp, sl = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
+            assert int(kp[-1]) == ref.npairs, case
+            assert np.array_equal(nl.half_number_of_partners().cpu().numpy(), ref.number_of_partners), case
+            assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), case
+
+
+@pytest.mark.parametrize("variant", [3, 4])
+def test_random_mask_pipeline_boxes_against_oracle(variant, monkeypatch):
+    """Twelve seeded random problems large enough for the hit-mask pipelines (VALU masks, matrix-core masks):
+    non-cubic boxes of 5..10 cells per axis with 15..38 particles per cell."""
+    monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
+    rng = np.random.default_rng(99 + variant)
+    for case in range(12):
+        rc = float(rng.uniform(1.0, 4.0))
+        mesh = rng.integers(5, 11, size=3)
+        box = tuple(float(m * rc * rng.uniform(1.0, 1.25)) for m in mesh)
+        n = int(int(mesh[0]) * int(mesh[1]) * int(mesh[2]) * rng.uniform(15.0, 38.0))
+        q, box = inputs.uniform_box(n, dtype=np.float32, seed=1000 + case, box=box)
+        ref = _po().build(q, rc, box)
+        nl, nop, kp, sl = gpu_build(q, rc, box)
+        info = nl.build_info()
+        assert info["masks"] and info["mfma"] == (variant == 4), (case, info)
+        assert int(kp[-1]) == ref.npairs, case
+        assert np.array_equal(nop, ref.number_of_partners), case
+        assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), case
