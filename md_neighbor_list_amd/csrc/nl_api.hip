@@ -69,6 +69,8 @@ struct nl_handle_s {
   int num_cus = 256;
   unsigned long long* dbg_buf = nullptr;
   int dbg_flags = 0, dbg_wg_per_cu = 4;  // diagnostics (NL_DEBUG_FLAGS, NL_DEBUG_WG_PER_CU)
+  int dbg_lds_pad = 0;                   // diagnostics (NL_DEBUG_LDS_PAD): extra dynamic LDS bytes on the COUNT_MASKS
+                                         // launch = fewer resident workgroups per CU (occupancy experiments)
   int32_t* cell_count = nullptr;  // [ncell] followed by the status word
   int32_t* cell_start = nullptr;  // [ncell + 1]
   int64_t* block_sum = nullptr;
@@ -246,7 +248,7 @@ template <typename T, bool FULL> void launch_sweep_kind(nl_handle_t h, int mode,
             return;
           }
         }
-        hipLaunchKernelGGL(k_sweep_count_masks_f32<FULL>, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+        hipLaunchKernelGGL(k_sweep_count_masks_f32<FULL>, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), h->dbg_lds_pad, s, a);
       } else
         hipLaunchKernelGGL((k_sweep<T, MODE_COUNT_MASKS, FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
     } else {
@@ -497,6 +499,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_DEBUG_FLAGS")) h->dbg_flags = atoi(v);
     if (const char* v = getenv("NL_DEBUG_WG_PER_CU")) h->dbg_wg_per_cu = std::max(1, atoi(v));
+    if (const char* v = getenv("NL_DEBUG_LDS_PAD")) h->dbg_lds_pad = std::max(0, atoi(v));
   }
   *out = h;
   return NL_OK;

@@ -56,6 +56,12 @@ __device__ __forceinline__ int32_t mf_stream_to_sorted(const CellCtx& c, int32_t
   return idx;
 }
 
+#ifdef MF_ABL_NO_MFMA  // ablation: the vector work on an accumulator that no MFMA produces (bv keeps the loads alive)
+#define MF_MFMA(A_, B_, C_) ((C_) + (B_))
+#else
+#define MF_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x4f32(A_, B_, C_, 0, 0, 0)
+#endif
+
 // One unit: the i-block of 16 rows starting at row i0 of the cell against half `half` of the ntiles staged tiles.
 // i_off: stream position of the cell's own first particle (the i-particles are part of their own stencil, so their
 // local coordinates and ids are already in LDS).
@@ -96,7 +102,11 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
       const uint32_t h = __float_as_uint(av) & (uint32_t)(gi[r] - gj);
       bits[r] = __builtin_amdgcn_alignbit(bits[r], h, 31);  // (bits << 1) | (h >> 31)
     }
+#ifdef MF_ABL_NO_UNC  // tools/mfma_bench ablation: no band check at all (timing only, results wrong)
+    if (false) {
+#else
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(m < delta) != 0, 0)) {
+#endif
       // rare (about 1 % of the tiles): some |r2 - rc2| is inside the error band of the matrix-core expression.
       // Re-test those elements with the reference's expression on the original coordinates and flip the bit just
       // written where the exact answer differs.  (Nothing here writes the accumulators: the common path keeps them
@@ -130,16 +140,20 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
       const int32_t tb = 32 * g, t_last = tb + n - 1;
       // Two accumulators in ping-pong: the MFMA of the next tile is issued before the vector work of the current
       // one.  Tile indices beyond the run are clamped (the result of such an MFMA is never consumed).
+#ifdef MF_ABL_NO_LDS  // ablation: every step reads the same tile (the loads are hoisted out of the loop)
+      auto tix = [&](int32_t) { return tb * MF_TILE; };
+#else
       auto tix = [&](int32_t t) { return min(t, t_last) * MF_TILE; };
+#endif
       float bv0 = bp[tix(tb)], bv1 = bp[tix(tb + 1)];
       int32_t g0 = gp[tix(tb)], g1 = gp[tix(tb + 1)];
-      f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, bv0, C, 0, 0, 0), acc1;
+      f32x4 acc0 = MF_MFMA(A, bv0, C), acc1;
       for (int32_t t = tb; t <= t_last; t += 2) {
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, bv1, C, 0, 0, 0);
+        acc1 = MF_MFMA(A, bv1, C);
         bv0 = bp[tix(t + 2)];
         const int32_t g0n = gp[tix(t + 2)];
         process(acc0, g0, t);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A, bv0, C, 0, 0, 0);
+        acc0 = MF_MFMA(A, bv0, C);
         bv1 = bp[tix(t + 3)];
         const int32_t g1n = gp[tix(t + 3)];
         if (t + 1 <= t_last) process(acc1, g1, t + 1);
@@ -152,7 +166,9 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int32_t irow = i0 + 4 * kq + r;
+#ifndef MF_ABL_NO_STORE
       if (irow < c.ni) a.masks[(size_t)(c.ibeg + irow) * MF_WORDS + g * 16 + lam] = bits[r];
+#endif
       total[r] += __popc(bits[r]);
     }
   };
