@@ -142,6 +142,19 @@ int nl_get_full_transposed(nl_handle_t h, const int32_t** list_dev, const int32_
  * full counts = 2P (neighlist_gpu.hpp:484-487); the C++ shim doubles it.  Synchronises. */
 int nl_number_of_pairs(nl_handle_t h, int64_t* npairs);
 
+/* ---------------------------------------------------------------------------------------------- a consumer */
+
+/* Truncated Lennard-Jones forces from the list of the last build (the reference stops at
+ * the list: its momentum array is allocated and never used, make_list.cpp:135,138-140).  q_dev: the positions the
+ * list was built from (or moved by less than the skin), same dtype and stride; f_dev: n x 4 values of that dtype,
+ * {fx, fy, fz, pe_i} with pe_i = half the pair energies of particle i; pairs beyond rc_force (<= the list's cut-off)
+ * are skipped; no minimum image, like the list.  After a NL_LIST_FULL build every row gathers its partners and
+ * writes its force once; after a NL_LIST_HALF build every pair is evaluated once and the reaction is added to the
+ * partner with floating-point atomics (f_dev is zeroed first).  Enqueued on `stream` (NULL = the null stream);
+ * waits for the build first. */
+int nl_lj_forces(nl_handle_t h, const void* q_dev, int32_t q_stride, double epsilon, double sigma, double rc_force,
+                 void* f_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------- introspection */
 
 int nl_get_mesh(nl_handle_t h, int32_t mesh[3], int64_t* ncell);

@@ -28,6 +28,7 @@ PROTOTYPES = {
     "nl_synchronize": (C.c_int, [_P]),
     "nl_get_half_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "nl_get_full_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
+    "nl_lj_forces": (C.c_int, [_P, _P, _I32, _D, _D, _D, _P, _P]),
     "nl_get_full_transposed": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.POINTER(_I32)]),
     "nl_number_of_pairs": (C.c_int, [_P, C.POINTER(_I64)]),
     "nl_get_mesh": (C.c_int, [_P, C.POINTER(_I32 * 3), C.POINTER(_I64)]),

@@ -835,3 +835,4 @@ int nl_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? 
 }  // extern "C"
 
 #include "nl_transpose.inc"
+#include "nl_consumer.inc"

@@ -56,6 +56,7 @@ class NeighListGPU:
             raise RuntimeError("NeighListGPU needs a HIP device; there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.dtype = dtype
+        self.search_length = float(search_length)
         self._h = C.c_void_p()
         check(
             self._lib.nl_create(C.byref(self._h), _lib.NL_F32 if dtype == torch.float32 else _lib.NL_F64,
@@ -202,6 +203,21 @@ class NeighListGPU:
         """neighlist_cpu.hpp:457-463 (view, valid until the next build)."""
         _, _, nop, _ = self._half()
         return _as_tensor(nop, (self._n_rows,), "<i4", self, self.device)
+
+    # ------------------------------------------------------------------ a consumer of the list
+    def lj_forces(self, q, epsilon=1.0, sigma=1.0, rc_force=None):
+        """Truncated Lennard-Jones forces and per-particle energies ``(n, 4) = {fx, fy, fz, pe_i}`` from the list of
+        the last build (nl_lj_forces): gather per row after a full-list build, pair-once with atomics after a half
+        build."""
+        n = self._check_q(q, None)
+        if n != self._n:
+            raise ValueError("q must hold the particles the list was built from")
+        f = torch.empty((n, 4), dtype=self.dtype, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self._lib.nl_lj_forces(self._h, q.data_ptr(), q.shape[1], float(epsilon), float(sigma),
+                                     float(self.search_length if rc_force is None else rc_force), f.data_ptr(), stream),
+              "nl_lj_forces")
+        return f
 
     # ------------------------------------------------------------------ introspection
     def sorted_state(self):
