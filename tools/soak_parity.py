@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Soak: many seeded random problems (all sweep variants, both binning paths, both dtypes, half and full lists)
+against the oracle.  usage: tools/soak_parity.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from md_neighbor_list_amd import NeighListGPU  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from tests.util import canonical_csr  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+bad = 0
+for case in range(cases):
+    dtype = np.float32 if rng.random() < 0.6 else np.float64
+    os.environ["NL_SWEEP_VARIANT"] = str(rng.integers(1, 5))
+    os.environ["NL_BINNING"] = str(rng.integers(0, 2))
+    rc = float(rng.uniform(0.5, 5.0))
+    mesh = rng.integers(3, 14, size=3)
+    box = tuple(float(m * rc * rng.uniform(1.0, 1.3)) for m in mesh)
+    ncell = int(mesh[0]) * int(mesh[1]) * int(mesh[2])
+    n = int(min(120000, max(1, ncell * rng.uniform(0.05, 60.0))))
+    q = np.zeros((n, 4), dtype=dtype)
+    q[:, :3] = rng.uniform(0.0, 1.0, size=(n, 3)) * np.array(box)
+    q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=dtype), dtype(0)))
+    full = rng.random() < 0.3
+    ref = po.build(q, rc, box)
+    nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64, full_list=full)
+    nl.Initialize(n)
+    qd = torch.from_numpy(q).cuda()
+    for rep in range(2):  # twice on the same handle
+        nl.MakeNeighList(qd, n, sync=(rep == 0))
+        nl.synchronize()
+        if full:
+            kp, lst, _ = (t.cpu().numpy() for t in nl.full_csr())
+            ok = int(kp[-1]) == 2 * ref.npairs
+            if ok:
+                rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(kp))
+                half = lst.astype(np.int64) > rows
+                hk = np.concatenate([[0], np.cumsum(np.bincount(rows[half], minlength=n))])
+                ok = np.array_equal(canonical_csr(hk, lst[half]), ref.canonical().sorted_list)
+        else:
+            kp, sl = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
+            ok = int(kp[-1]) == ref.npairs and np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {case} rep {rep}: n={n} box={box} rc={rc} dtype={dtype.__name__} full={full} "
+                  f"variant={os.environ['NL_SWEEP_VARIANT']} binning={os.environ['NL_BINNING']} info={nl.build_info()}", flush=True)
+    if case % 50 == 49:
+        print(f"{case + 1} cases, {bad} mismatches", flush=True)
+print(f"soak done: {cases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
