@@ -83,6 +83,17 @@ int nl_set_capacity(nl_handle_t h, int64_t max_pairs);
 enum nl_list_kind { NL_LIST_HALF = 0, NL_LIST_FULL = 1 };
 int nl_set_list_kind(nl_handle_t h, int kind);
 
+/* Distances across the periodic faces.  0 (default) = the reference: the 27-cell stencil wraps cell indices but the
+ * distance is taken between the coordinates as given (neighlist_cpu.hpp:107-132,219-223), i.e. an open box.
+ * 1 = minimum image (not in the reference): a stencil cell reached through a periodic face
+ * is tested at its image, dx = (x_j -+ L) - x_i with the shifted coordinate rounded to the position type first; a
+ * particle whose cell index was wrapped (coordinate outside [0, L), or rounding up to the box edge) is itself taken
+ * at its image next to that cell.  The pair is decided once, by the row that stores it (the smaller id); with
+ * NL_LIST_FULL both rows decide on their own and may differ for a pair within one ulp of the cut-off across a face.
+ * Slab builds: the two ghost layers of the box-end ranks are the periodic images (the caller sends the layers
+ * unshifted, as for the open box).  Takes effect at the next build. */
+int nl_set_periodic(nl_handle_t h, int minimum_image);
+
 int nl_destroy(nl_handle_t h);
 
 /* --------------------------------------------------------------------------------------------------- build */

@@ -45,6 +45,7 @@ struct nl_handle_s {
   int64_t capacity = 0;      // list entries (half pairs, or twice as many for a full list)
   bool capacity_user = false;
   int list_kind = NL_LIST_HALF;
+  bool pbc = false;          // minimum-image mode (nl_set_periodic)
 
   // device buffers
   int32_t* rank = nullptr;
@@ -157,6 +158,9 @@ template <typename T> Grid<T> make_grid(nl_handle_t h, int32_t n_rows, int32_t z
   g.slab = slab;
   g.z_origin = slab ? ((z_lo - 1) % h->m[2] + h->m[2]) % h->m[2] : 0;
   g.n_rows = n_rows;
+  g.pbc = h->pbc ? 1 : 0;
+  g.z_first = slab ? z_lo - 1 : 0;
+  for (int d = 0; d < 3; d++) g.L[d] = (T)h->L[d];
   return g;
 }
 
@@ -209,6 +213,8 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.masks = h->masks;
   for (int d = 0; d < 3; d++) a.ms[d] = sizeof(T) == 4 ? (T)h->ms_f[d] : (T)(h->L[d] / h->m[d]);
   a.delta = (T)h->mfma_delta;
+  a.pbc = h->pbc ? 1 : 0;
+  for (int d = 0; d < 3; d++) a.L[d] = (T)h->L[d];
   a.z_origin = h->b_slab ? h->b_zlo - 1 : 0;
   a.dbg = h->dbg_flags;
   a.dbg_buf = h->dbg_buf;
@@ -295,7 +301,8 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   // Hit masks pay off while a cell's stencil fits one LDS batch; where the mean stencil (27 cells) is close to or
   // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
   h->b_full = h->list_kind == NL_LIST_FULL;
-  h->b_variant = h->b_full ? (h->sweep_variant >= 3 ? 3 : 1) : h->sweep_variant;
+  // (the persistent and matrix-core variants implement the reference's open-box distances and the half list only)
+  h->b_variant = (h->b_full || h->pbc) ? (h->sweep_variant >= 3 ? 3 : 1) : h->sweep_variant;
   h->b_use_masks = h->b_variant >= 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
   h->b_use_mfma = h->b_use_masks && h->b_variant == 4 && sizeof(T) == 4;
   const int32_t nbp = (n + 255) / 256;
@@ -566,6 +573,18 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   h->n_max = n_max;
   if ((rc = estimate_capacity(h))) return rc;
   h->t_valid = false;
+  return NL_OK;
+}
+
+int nl_set_periodic(nl_handle_t h, int minimum_image) {
+  if (!h) return NL_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->pending) (void)finish(h, false);
+  if ((minimum_image != 0) != h->pbc) {
+    h->pbc = minimum_image != 0;
+    h->built = false;
+    h->t_valid = false;
+  }
   return NL_OK;
 }
 

@@ -43,6 +43,11 @@ template <typename T> struct Grid {
   int32_t z_origin;  // global z layer of local layer 0
   int32_t slab;      // 0: periodic wrap in z, every cell owned; 1: layers 0 and mzl-1 are ghosts
   int32_t n_rows;    // particles [0, n_rows) are owned (get rows), [n_rows, n) are ghosts
+  // minimum-image mode (nl_set_periodic; not in the reference, which wraps cells but never distances):
+  int32_t pbc;       // 1: a particle whose cell index was wrapped (or that sits in a slab's wrapped ghost layer) is
+                     //    stored at its periodic image next to that cell: coordinate -+ L
+  int32_t z_first;   // slab: global layer that local layer 0 stands for, z_lo - 1 (may be -1)
+  T L[3];            // box lengths rounded to T
 };
 
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
@@ -57,16 +62,20 @@ __device__ __forceinline__ double sub_rn(double a, double b) { return __dsub_rn(
 // Returns -1 where the reference would index out of bounds, -2 for a particle outside this rank's layers.
 template <typename T>
 __device__ __forceinline__ int32_t local_cell(const Grid<T>& g, T x, T y, T z, int32_t* lz_out,
-                                              int32_t* row_out = nullptr) {
+                                              int32_t* row_out = nullptr, T* shift_out = nullptr) {
   const T t[3] = {mul_rn(x, g.ims[0]), mul_rn(y, g.ims[1]), mul_rn(z, g.ims[2])};
   int32_t idx[3];
+  T sh[3] = {0, 0, 0};  // minimum-image mode: what to add to the coordinate so that it lies in / next to its cell
   bool bad = false;
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     if (!(t[d] > (T)-2147483000.0 && t[d] < (T)2147483000.0)) bad = true;  // NaN / overflow: UB in the reference
     int32_t v = (int32_t)t[d];
-    if (v < 0) v += g.m[d];
-    if (v >= g.m[d]) v -= g.m[d];
+    // (minimum-image mode takes the floor: the reference's truncation files a particle at -0.3 cells into cell 0,
+    // harmless in its open box, wrong for images)
+    if (g.pbc && t[d] < (T)0 && (T)v != t[d]) v -= 1;
+    if (v < 0) v += g.m[d], sh[d] = g.L[d];
+    if (v >= g.m[d]) v -= g.m[d], sh[d] = -g.L[d];
     if (v < 0 || v >= g.m[d]) bad = true;
     idx[d] = v;
   }
@@ -74,6 +83,12 @@ __device__ __forceinline__ int32_t local_cell(const Grid<T>& g, T x, T y, T z, i
   int32_t lz = idx[2] - g.z_origin;
   if (lz < 0) lz += g.m[2];
   if (lz >= g.mzl) return -2;
+  if (g.slab) {  // the layer this local layer stands for may lie beyond the box end: the particle is its image there
+    const int32_t acting = g.z_first + lz;
+    if (acting < 0) sh[2] -= g.L[2];
+    if (acting >= g.m[2]) sh[2] += g.L[2];
+  }
+  if (shift_out) shift_out[0] = sh[0], shift_out[1] = sh[1], shift_out[2] = sh[2];
   *lz_out = lz;
   if (row_out) *row_out = idx[1] + lz * g.m[1];  // the row of x-cells the particle lies in
   return idx[0] + (idx[1] + lz * g.m[1]) * g.m[0];
@@ -134,10 +149,12 @@ __global__ void __launch_bounds__(256) k_reorder(const T* __restrict__ q, int32_
   T x, y, z;
   load_xyz(q, stride, i, x, y, z);
   int32_t lz = 0;
-  const int32_t c = local_cell(g, x, y, z, &lz);
+  T sh[3];
+  const int32_t c = local_cell(g, x, y, z, &lz, nullptr, sh);
   const int32_t dst = cell_start[c] + r;
   Pos<T> p;
   p.x = x, p.y = y, p.z = z;
+  if (g.pbc) p.x = add_rn(x, sh[0]), p.y = add_rn(y, sh[1]), p.z = add_rn(z, sh[2]);
   if (gid == reinterpret_cast<const int32_t*>(1)) {  // NL_GID_IN_W: the id travels in the w component of the Vec
     if constexpr (sizeof(T) == 4) p.gid = __float_as_int(q[(size_t)i * 4 + 3]);
     else p.gid = (int32_t)__double_as_longlong(q[(size_t)i * 4 + 3]);
@@ -389,11 +406,14 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
     T x, y, z;
     load_xyz(q, stride, i, x, y, z);
     int32_t lz = 0, row = 0;
-    const int32_t c = local_cell(g, x, y, z, &lz, &row);
+    T sh[3];
+    const int32_t c = local_cell(g, x, y, z, &lz, &row, sh);
     if (c < 0) continue;
     const int32_t dst = atomicAdd(&cursor[row], 1);
     Pos<T> p;
     p.x = x, p.y = y, p.z = z;
+    // (minimum-image mode: x keeps its value until k_bin_cells has derived the x-cell from it)
+    if (g.pbc) p.y = add_rn(y, sh[1]), p.z = add_rn(z, sh[2]);
     if (gid == reinterpret_cast<const int32_t*>(1)) {  // NL_GID_IN_W: the id travels in the w component of the Vec
       if constexpr (sizeof(T) == 4) p.gid = __float_as_int(q[(size_t)i * 4 + 3]);
       else p.gid = (int32_t)__double_as_longlong(q[(size_t)i * 4 + 3]);
@@ -422,7 +442,9 @@ __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, con
   __syncthreads();
   // x-cell exactly as local_cell computes it (the particle passed the range checks in k_bin_rows)
   auto xcell = [&](T x) {
-    int32_t v = (int32_t)mul_rn(x, g.ims[0]);
+    const T tx = mul_rn(x, g.ims[0]);
+    int32_t v = (int32_t)tx;
+    if (g.pbc && tx < (T)0 && (T)v != tx) v -= 1;
     if (v < 0) v += mx;
     if (v >= mx) v -= mx;
     return v;
@@ -450,8 +472,15 @@ __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, con
   }
   if (r == nrows - 1 && tid == 0) cell_start[(size_t)nrows * mx] = end;
   for (int32_t k = beg + tid; k < end; k += 256) {
-    const Pos<T> p = tmp[k];
+    Pos<T> p = tmp[k];
     const int32_t dst = beg + atomicAdd(&cnt[xcell(p.x)], 1);
+    if (g.pbc) {  // minimum-image mode: a wrapped x index means the particle is stored at its image
+      const T tx = mul_rn(p.x, g.ims[0]);
+      int32_t v = (int32_t)tx;
+      if (tx < (T)0 && (T)v != tx) v -= 1;
+      if (v < 0) p.x = add_rn(p.x, g.L[0]);
+      if (v >= mx) p.x = add_rn(p.x, -g.L[0]);
+    }
     sorted[dst] = p;
     sorted_row[dst] = tmp_row[k];
   }
@@ -496,6 +525,9 @@ template <typename T> struct SweepArgs {
   const int64_t* __restrict__ total;
   int64_t capacity;
   uint32_t* __restrict__ status;
+  T L[3];                         // box lengths rounded to T (minimum-image mode)
+  int32_t pbc;                    // minimum-image mode: stencil cells reached through the periodic wrap are staged
+                                  // at their image, coordinate -+ L (nl_set_periodic; not in the reference)
   T ms[3];                        // cell edge rounded to T (neighlist_cpu.hpp:404-406); k_sweep_mfma_f32 only
   T delta;                        // k_sweep_mfma_f32: |r2 - rc2| below this is re-tested exactly
   int32_t z_origin;               // global z layer of local layer 0
@@ -607,6 +639,8 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
 struct CellCtx {
   int32_t ibeg, ni, seg_src, seg_len, seg_off, total_j;
   int32_t cx, cy, cz;  // the i-cell (cz: local layer)
+  int32_t wrap;        // per segment: (wx + 1) | (wy + 1) << 2 | (wz + 1) << 4, w = -1 / 0 / +1: the segment's cells are
+                       // reached through the low / no / high periodic face of that axis
 };
 
 // Maps the workgroup to its i-cell (XCD-aware) and loads the segment table.  Returns false for an empty cell.
@@ -627,7 +661,7 @@ template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs
 
   // (the empty-cell exit comes after the segment-table loads so that both round trips are in flight together)
   // Segment table, one segment per lane (lanes >= 18 hold empty segments): 9 (dz,dy) rows x 2 x-parts.
-  c.seg_src = 0, c.seg_len = 0;
+  c.seg_src = 0, c.seg_len = 0, c.wrap = 0x15;
   if (lane < NSEG) {
     // slots 0..8 = first x-part of the nine (dz,dy) rows (never empty in the interior), 9..17 = the wrapped part
     const int32_t s = lane % 9, part = lane / 9, dz = s / 3 - 1, dy = s % 3 - 1;
@@ -649,6 +683,11 @@ template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs
     const int32_t rowbase = (y + z * a.my) * a.mx;
     c.seg_src = a.cell_start[rowbase + x0];
     c.seg_len = a.cell_start[rowbase + x1] - c.seg_src;
+    // through which periodic faces this segment is reached (used in minimum-image mode only)
+    const int32_t wx = (cx == 0 && part == 0) ? -1 : (cx == a.mx - 1 && part == 1) ? 1 : 0;
+    const int32_t wy = cy + dy < 0 ? -1 : cy + dy >= a.my ? 1 : 0;
+    const int32_t wz = a.slab ? 0 : cz + dz < 0 ? -1 : cz + dz >= a.mzl ? 1 : 0;
+    c.wrap = (wx + 1) | (wy + 1) << 2 | (wz + 1) << 4;
   }
   if (c.ni == 0) return false;
   c.seg_off = scan32_dpp(c.seg_len) - c.seg_len;  // exclusive offsets in the staged stream
@@ -682,11 +721,19 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       if (len == 0) continue;
       const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
       const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg) - win0;
+      // minimum-image mode: a segment reached through a periodic face is staged at its image (uniform per segment)
+      const int32_t wr = a.pbc ? __builtin_amdgcn_readlane(c.wrap, sg) : 0x15;
+      const bool shifted = wr != 0x15;
+      const T sx = (T)((wr & 3) - 1) * a.L[0], sy = (T)(((wr >> 2) & 3) - 1) * a.L[1], sz = (T)(((wr >> 4) & 3) - 1) * a.L[2];
       for (int32_t k = lane; k < len; k += 2 * WAVE) {
         const int32_t k1 = k + WAVE;
         const bool p1 = k1 < len;
-        const Pos<T> v0 = a.sorted[src + k];
-        const Pos<T> v1 = a.sorted[src + (p1 ? k1 : k)];
+        Pos<T> v0 = a.sorted[src + k];
+        Pos<T> v1 = a.sorted[src + (p1 ? k1 : k)];
+        if (shifted) {
+          v0.x = add_rn(v0.x, sx), v0.y = add_rn(v0.y, sy), v0.z = add_rn(v0.z, sz);
+          v1.x = add_rn(v1.x, sx), v1.y = add_rn(v1.y, sy), v1.z = add_rn(v1.z, sz);
+        }
         if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) tile[off + k] = v0;
         if (p1 && (nbatch == 1 || (uint32_t)(off + k1) < (uint32_t)CAP)) tile[off + k1] = v1;
       }

@@ -48,7 +48,8 @@ class NeighListGPU:
     plays the role of the reference's compile-time ``Dtype``/``Vec`` choice (make_list.cu:6-12).
     """
 
-    def __init__(self, search_length, Lx, Ly, Lz, dtype=torch.float32, device=None, full_list=False):
+    def __init__(self, search_length, Lx, Ly, Lz, dtype=torch.float32, device=None, full_list=False,
+                 minimum_image=False):
         if dtype not in (torch.float32, torch.float64):
             raise TypeError("dtype must be torch.float32 or torch.float64")
         self._lib = _lib.load()  # raises when the HIP extension is missing
@@ -71,8 +72,11 @@ class NeighListGPU:
         self._n = 0
         self._n_rows = 0
         self.full_list = False
+        self.minimum_image = False
         if full_list:
             self.set_full_list(True)
+        if minimum_image:
+            self.set_periodic(True)
         self._q = None  # keeps the positions of an asynchronous build alive
 
     def __del__(self):
@@ -90,6 +94,12 @@ class NeighListGPU:
 
     def set_capacity(self, max_pairs):
         check(self._lib.nl_set_capacity(self._h, int(max_pairs)), "nl_set_capacity")
+
+    def set_periodic(self, minimum_image=True):
+        """Minimum-image distances across the periodic faces (nl_set_periodic).  The reference, and the default here,
+        wrap the cell stencil but measure distances in an open box."""
+        check(self._lib.nl_set_periodic(self._h, 1 if minimum_image else 0), "nl_set_periodic")
+        self.minimum_image = bool(minimum_image)
 
     def set_full_list(self, full=True):
         """Builds produce the FULL list (every pair in both rows: the reference GPU kernels' contract,

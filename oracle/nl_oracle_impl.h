@@ -262,3 +262,119 @@ int SUF(nl_oracle_bruteforce)(const REAL* q, int32_t stride, int64_t N, double r
   *npairs = P;
   return NLO_OK;
 }
+
+/*
+ * Minimum-image half list.  NOT a restatement of the reference -- it has no such mode --
+ * but the definition the HIP path's nl_set_periodic(1) is tested against.  Written independently of the device code:
+ *   - the cell index of a coordinate is FLOOR(q * ims) here (GenHash truncates toward zero, which files a particle
+ *     at -0.3 cells into cell 0; harmless for the reference's open box, wrong for images), wrapped once by +-m;
+ *   - every particle is first taken at the image that lies in its (wrapped) cell: per axis, the coordinate + L if
+ *     the index was negative, - L if it was >= m, rounded to REAL;
+ *   - for particle i (cell c, smaller id) and particle j (larger id) in one of the 27 neighbour cells of c, reached
+ *     through offset (jx,jy,jz): s_d = -L_d if c_d + j_d < 0, +L_d if c_d + j_d >= m_d, else 0 (L_d rounded to REAL);
+ *     d = (q_j + s) - q_i with the shifted coordinate rounded to REAL first; r2 = dx*dx + dy*dy + dz*dz;
+ *     the pair is kept unless (double)r2 > rc2.
+ * Needs >= 3 cells per axis.  Output: canonical CSR (ascending partners), as the brute force.
+ */
+int SUF(nl_oracle_build_pbc)(const REAL* q, int32_t stride, int64_t N, double rc, double Lx, double Ly, double Lz,
+                             int32_t* number_of_partners, int64_t* key_pointer, int32_t** sorted_list,
+                             int64_t* npairs) {
+  SUF(grid) g;
+  if (N < 0 || N > 2147483647LL || stride < 3) return NLO_ERR_ARG;
+  int rc_ = SUF(grid_init)(&g, rc, Lx, Ly, Lz);
+  if (rc_) return rc_;
+  if (g.m[0] < 3 || g.m[1] < 3 || g.m[2] < 3) return NLO_ERR_ARG;
+  const REAL L[3] = {(REAL)Lx, (REAL)Ly, (REAL)Lz};
+  const int64_t M = g.ncell;
+  REAL* e = (REAL*)malloc(sizeof(REAL) * 3 * (size_t)(N > 0 ? N : 1)); /* effective coordinates */
+  int32_t* cidx = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(N > 0 ? N : 1));
+  int64_t* cell_beg = (int64_t*)calloc((size_t)(M + 2), sizeof(int64_t));
+  int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  int64_t cap = N * 64 + 1024, P = 0;
+  int32_t* out = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+  int ret = NLO_OK;
+  if (!e || !cidx || !cell_beg || !ids || !out) {
+    ret = NLO_ERR_NOMEM;
+    goto done;
+  }
+  for (int64_t i = 0; i < N; i++) {
+    const REAL* qi = q + (size_t)i * stride;
+    for (int d = 0; d < 3; d++) {
+      const REAL t = qi[d] * g.ims[d];
+      if (!(t > (REAL)-2147483000.0 && t < (REAL)2147483000.0)) {
+        ret = NLO_ERR_OUT_OF_BOX;
+        goto done;
+      }
+      int32_t v = (int32_t)t;
+      if (t < 0 && (REAL)v != t) v -= 1; /* floor */
+      REAL x = qi[d];
+      if (v < 0) v += g.m[d], x = qi[d] + L[d];
+      if (v >= g.m[d]) v -= g.m[d], x = qi[d] - L[d];
+      if (v < 0 || v >= g.m[d]) {
+        ret = NLO_ERR_OUT_OF_BOX;
+        goto done;
+      }
+      cidx[3 * i + d] = v;
+      e[3 * i + d] = x;
+    }
+    cell_beg[SUF(hash_idx)(&g, cidx + 3 * i) + 2]++;
+  }
+  for (int64_t c = 0; c < M; c++) cell_beg[c + 2] += cell_beg[c + 1];
+  for (int64_t i = 0; i < N; i++) ids[cell_beg[SUF(hash_idx)(&g, cidx + 3 * i) + 1]++] = (int32_t)i;
+  /* now cell_beg[c] .. cell_beg[c+1] are the particles of cell c */
+  key_pointer[0] = 0;
+  for (int64_t i = 0; i < N; i++) {
+    const int64_t row0 = P;
+    for (int32_t jz = -1; jz < 2; jz++)
+      for (int32_t jy = -1; jy < 2; jy++)
+        for (int32_t jx = -1; jx < 2; jx++) {
+          const int32_t off[3] = {jx, jy, jz};
+          int32_t nc[3];
+          REAL s[3];
+          for (int d = 0; d < 3; d++) {
+            nc[d] = cidx[3 * i + d] + off[d];
+            s[d] = 0;
+            if (nc[d] < 0) nc[d] += g.m[d], s[d] = -L[d];
+            if (nc[d] >= g.m[d]) nc[d] -= g.m[d], s[d] = L[d];
+          }
+          const int64_t c = SUF(hash_idx)(&g, nc);
+          for (int64_t b = cell_beg[c]; b < cell_beg[c + 1]; b++) {
+            const int32_t j = ids[b];
+            if (j <= i) continue;
+            const REAL xs = e[3 * (int64_t)j] + s[0], ys = e[3 * (int64_t)j + 1] + s[1], zs = e[3 * (int64_t)j + 2] + s[2];
+            const REAL dx = xs - e[3 * i], dy = ys - e[3 * i + 1], dz = zs - e[3 * i + 2];
+            const REAL r2 = dx * dx + dy * dy + dz * dz;
+            if ((double)r2 > g.rc2) continue;
+            if (P == cap) {
+              cap *= 2;
+              int32_t* o2 = (int32_t*)realloc(out, sizeof(int32_t) * (size_t)cap);
+              if (!o2) {
+                ret = NLO_ERR_NOMEM;
+                goto done;
+              }
+              out = o2;
+            }
+            out[P++] = j;
+          }
+        }
+    /* ascending partners */
+    for (int64_t a = row0 + 1; a < P; a++) {
+      const int32_t v = out[a];
+      int64_t b = a - 1;
+      while (b >= row0 && out[b] > v) out[b + 1] = out[b], b--;
+      out[b + 1] = v;
+    }
+    number_of_partners[i] = (int32_t)(P - row0);
+    key_pointer[i + 1] = P;
+  }
+  *sorted_list = out;
+  out = NULL;
+  *npairs = P;
+done:
+  free(e);
+  free(cidx);
+  free(cell_beg);
+  free(ids);
+  free(out);
+  return ret;
+}

@@ -74,6 +74,10 @@ def _lib():
             f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
                           C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+            f = getattr(lib, "nl_oracle_build_pbc_" + s)
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                          C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
             f = getattr(lib, "nl_oracle_bruteforce_" + s)
             f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_int,
@@ -110,6 +114,21 @@ def build(q, rc, box) -> HalfList:
     ptr, npairs = C.c_void_p(), C.c_int64()
     rc_ = getattr(_lib(), "nl_oracle_build_" + s)(q.ctypes.data, q.shape[1], n, rc, box[0], box[1], box[2],
                                                   nop.ctypes.data, kp.ctypes.data, C.byref(ptr), C.byref(npairs))
+    if rc_:
+        raise OracleError(rc_)
+    return HalfList(nop, kp, _take(ptr, npairs.value))
+
+
+def build_pbc(q, rc, box) -> HalfList:
+    """Minimum-image half list: the definition nl_set_periodic(1) is tested against; canonical
+    order.  Not a restatement of the reference, which has no such mode."""
+    q, s = _prep(q)
+    n = q.shape[0]
+    nop = np.zeros(n, dtype=np.int32)
+    kp = np.zeros(n + 1, dtype=np.int64)
+    ptr, npairs = C.c_void_p(), C.c_int64()
+    rc_ = getattr(_lib(), "nl_oracle_build_pbc_" + s)(q.ctypes.data, q.shape[1], n, rc, box[0], box[1], box[2],
+                                                      nop.ctypes.data, kp.ctypes.data, C.byref(ptr), C.byref(npairs))
     if rc_:
         raise OracleError(rc_)
     return HalfList(nop, kp, _take(ptr, npairs.value))

@@ -35,7 +35,8 @@ def worker(rank, world, port, mode, case, ret):
             iz = slab.z_layer(torch.from_numpy(q), box, rc).numpy()
             q = np.ascontiguousarray(q[~np.isin(iz, case[5])])
             n = len(q)
-        dev = "cuda" if mode == "hip" else "cpu"
+        pbc = mode == "hip_pbc"  # minimum-image mode (nl_set_periodic): the end ranks' ghost layers are images
+        dev = "cuda" if mode in ("hip", "hip_pbc") else "cpu"
         qt = torch.from_numpy(q).to(dev)
         st = slab.setup(qt, None, box, rc)
         if mode == "oracle":
@@ -61,7 +62,7 @@ def worker(rank, world, port, mode, case, ret):
             from md_neighbor_list_amd import NeighListGPU
 
             tdt = torch.float32 if q.dtype == np.float32 else torch.float64
-            nl = NeighListGPU(rc, *box, dtype=tdt)
+            nl = NeighListGPU(rc, *box, dtype=tdt, minimum_image=pbc)
             nl.Initialize(st.q_all.shape[0])
             slab.build(nl, st, sync=True)
             kp = nl.key_pointer().cpu().numpy()
@@ -77,7 +78,7 @@ def worker(rank, world, port, mode, case, ret):
         gathered = [None] * world
         dist.all_gather_object(gathered, (mine, st.n_rows, st.n_ghost_lo, st.n_ghost_hi))
         if rank == 0:
-            ref = po.build(q, rc, box)
+            ref = po.build_pbc(q, rc, box) if pbc else po.build(q, rc, box)
             want = np.sort(pairs_of(ref.key_pointer, ref.sorted_list))
             got = np.sort(np.concatenate([g[0] for g in gathered]))
             assert sum(g[1] for g in gathered) == n

@@ -460,3 +460,46 @@ def test_md_loop_with_skin_rebuilds_and_resorting(monkeypatch):
     # (the potential is truncated at rc without a shift: every pair crossing rc moves the energy by 0.016 eps, so the
     # total is conserved only to a few 1e-3; an integration or list error would show at the 1e-1 level)
     assert abs(sim.energy() - e0) < 5e-3 * abs(e0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_minimum_image_mode_against_its_oracle(dtype):
+    """nl_set_periodic(1) (not in the reference): bit-exact against oracle.build_pbc, which is
+    itself checked against a float64 brute force (tests/test_oracle.py).  Small and large meshes, particles outside
+    [0, L) and on the faces, the mask pipeline and the two-sweep path, half and full list."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    rng = np.random.default_rng(314)
+    for case in range(14):
+        rc = float(rng.uniform(1.0, 3.5))
+        mesh = rng.integers(3, 4 if case < 4 else 11, size=3)
+        box = tuple(float(m * rc * rng.uniform(1.0, 1.3)) for m in mesh)
+        ncell = int(mesh[0]) * int(mesh[1]) * int(mesh[2])
+        n = int(ncell * rng.uniform(5.0, 70.0 if case % 3 == 0 else 36.0))
+        q = np.zeros((n, 4), dtype=dtype)
+        q[:, :3] = rng.uniform(-0.3, 1.3, size=(n, 3)) * np.array(box)
+        q[:30, :3] = np.round(q[:30, :3] / np.array(box)) * np.array(box)
+        q[:, :3] = np.clip(q[:, :3], -0.9 * np.array(box), 1.9 * np.array(box))
+        ref = _po().build_pbc(q, rc, box)
+        full = case % 4 == 3
+        nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64,
+                          minimum_image=True, full_list=full)
+        nl.Initialize(n)
+        nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+        if full:
+            kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr())
+            want_kp, want_list, want_cnt = _full_from_half(ref)
+            assert np.array_equal(kp.astype(np.int64), want_kp), case
+            assert np.array_equal(canonical_csr(kp, lst), want_list), case
+        else:
+            kp, sl = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
+            assert int(kp[-1]) == ref.npairs, (case, int(kp[-1]), ref.npairs)
+            assert np.array_equal(nl.half_number_of_partners().cpu().numpy(), ref.number_of_partners), case
+            assert np.array_equal(canonical_csr(kp, sl), ref.sorted_list), case
+    # and the open box (the reference's semantics) is a different list on the same positions
+    nl.set_periodic(False)
+    nl.set_full_list(False)
+    nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+    assert nl.half_number_of_pairs() < ref.npairs

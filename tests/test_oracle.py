@@ -99,3 +99,31 @@ def test_out_of_box_is_reported():
         po.build(q, 3.3, box)
     c, mesh = po.cells(q, 3.3, box)
     assert c[7] == -1 and np.all(c[np.arange(100) != 7] >= 0) and tuple(mesh) == (3, 3, 3)
+
+
+def test_minimum_image_oracle_against_float64_brute_force():
+    """The minimum-image definition (oracle build_pbc) against an O(N^2) float64 numpy minimum
+    image on boxes of 3..5 cells per axis, with particles outside [0, L) and on the faces."""
+    rng = np.random.default_rng(5)
+    for case in range(6):
+        rc = float(rng.uniform(1.0, 3.0))
+        mesh = rng.integers(3, 6, size=3)
+        box = tuple(float(m * rc * rng.uniform(1.0, 1.3)) for m in mesh)
+        n = 700
+        q = np.zeros((n, 4), dtype=np.float64)
+        q[:, :3] = rng.uniform(-0.2, 1.2, size=(n, 3)) * np.array(box)  # some outside the box: taken at their image
+        q[:20, :3] = np.round(q[:20, :3] / np.array(box)) * np.array(box)  # on the faces 0 and L
+        q[:, :3] = np.clip(q[:, :3], -0.95 * np.array(box), 1.95 * np.array(box))
+        got = po.build_pbc(q, rc, box)
+        d = q[None, :, :3] - q[:, None, :3]
+        d -= np.round(d / np.array(box)) * np.array(box)
+        r2 = (d * d).sum(axis=2)
+        iu = np.triu(np.ones((n, n), dtype=bool), 1)
+        near = np.abs(r2 - rc * rc) < 1e-9  # ties decided by rounding: excluded from the comparison
+        want = (r2 <= rc * rc) & iu
+        have = np.zeros((n, n), dtype=bool)
+        rows = np.repeat(np.arange(n), np.diff(got.key_pointer))
+        have[rows, got.sorted_list] = True
+        assert not (have & ~iu).any()
+        assert np.array_equal(have[~near], want[~near]), case
+        assert got.npairs > 0

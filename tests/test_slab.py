@@ -53,3 +53,13 @@ def test_slab_union_equals_global_list_cpu(world, case):
 def test_slab_union_equals_global_list_gpu(world, case):
     res = run(world, "hip", case)
     assert res[0] == "ok"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case", [
+    (2, (30000, (20.0, 22.0, 40.0), 3.3, "float32", 91)),   # 12 layers: the end ranks' ghosts are periodic images
+    (3, (30000, (21.0, 20.0, 31.0), 3.3, "float64", 92)),   # 9 layers, 3 + 3 + 3
+])
+def test_slab_union_equals_global_minimum_image_list_gpu(world, case):
+    res = run(world, "hip_pbc", case)
+    assert res[0] == "ok"
