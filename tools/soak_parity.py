@@ -28,8 +28,12 @@ for case in range(cases):
     q[:, :3] = rng.uniform(0.0, 1.0, size=(n, 3)) * np.array(box)
     q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=dtype), dtype(0)))
     full = rng.random() < 0.3
-    ref = po.build(q, rc, box)
-    nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64, full_list=full)
+    pbc = rng.random() < 0.3
+    if pbc:  # minimum-image mode: also particles outside the box
+        q[:, :3] = np.clip(rng.uniform(-0.3, 1.3, size=(n, 3)) * np.array(box), -0.9 * np.array(box), 1.9 * np.array(box))
+    ref = (po.build_pbc(q, rc, box) if pbc else po.build(q, rc, box)).canonical()
+    nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64, full_list=full,
+                      minimum_image=pbc)
     nl.Initialize(n)
     qd = torch.from_numpy(q).cuda()
     for rep in range(2):  # twice on the same handle
@@ -42,14 +46,14 @@ for case in range(cases):
                 rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(kp))
                 half = lst.astype(np.int64) > rows
                 hk = np.concatenate([[0], np.cumsum(np.bincount(rows[half], minlength=n))])
-                ok = np.array_equal(canonical_csr(hk, lst[half]), ref.canonical().sorted_list)
+                ok = np.array_equal(canonical_csr(hk, lst[half]), ref.sorted_list)
         else:
             kp, sl = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
-            ok = int(kp[-1]) == ref.npairs and np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+            ok = int(kp[-1]) == ref.npairs and np.array_equal(canonical_csr(kp, sl), ref.sorted_list)
         if not ok:
             bad += 1
             print(f"MISMATCH case {case} rep {rep}: n={n} box={box} rc={rc} dtype={dtype.__name__} full={full} "
-                  f"variant={os.environ['NL_SWEEP_VARIANT']} binning={os.environ['NL_BINNING']} info={nl.build_info()}", flush=True)
+                  f"pbc={pbc} variant={os.environ['NL_SWEEP_VARIANT']} binning={os.environ['NL_BINNING']} info={nl.build_info()}", flush=True)
     if case % 50 == 49:
         print(f"{case + 1} cases, {bad} mismatches", flush=True)
 print(f"soak done: {cases} cases, {bad} mismatches")
