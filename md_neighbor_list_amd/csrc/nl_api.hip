@@ -550,6 +550,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
     const size_t nrows = (size_t)h->m[1] * h->m[2];
     // chunk per block: 4096 particles, more for very large N so that blk_base stays small
     h->bin_chunk = 4096;
+    if (const char* v = getenv("NL_DEBUG_BIN_CHUNK")) h->bin_chunk = std::max(1024, atoi(v));  // diagnostics
     while ((n + h->bin_chunk - 1) / h->bin_chunk > 1024) h->bin_chunk *= 2;
     h->bin_blocks = (int32_t)((n + h->bin_chunk - 1) / h->bin_chunk);
     if (h->bin_blocks < 1) h->bin_blocks = 1;
