@@ -40,6 +40,7 @@ struct nl_handle_s {
   float rc2_f = 0;
   float ms_f[3];       // cell edge as the reference's float Vec holds it (neighlist_cpu.hpp:389-391)
   float mfma_delta = 0;  // k_sweep_mfma_f32: half-width of the band that is re-tested exactly (mfma_delta())
+  double mfma_delta16 = 0, mfma_scale = 1;  // k_sweep_mfma_f16: band (unscaled units) and coordinate scale
 
   int32_t n_max = 0;
   int64_t capacity = 0;      // list entries (half pairs, or twice as many for a full list)
@@ -67,6 +68,7 @@ struct nl_handle_s {
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps; 2: persistent LDS-DMA sweeps (fp32);
                                    // 3 (default): VALU COUNT keeping hit masks + mask expansion;
                                    // 4: as 3 with the fp32 COUNT on the matrix cores (k_sweep_mfma_f32; slower so far)
+                                   // 5: as 4 with the f16 two-piece MFMA (k_sweep_mfma_f16)
   int num_cus = 256;
   unsigned long long* dbg_buf = nullptr;
   int dbg_flags = 0, dbg_wg_per_cu = 4;  // diagnostics (NL_DEBUG_FLAGS, NL_DEBUG_WG_PER_CU)
@@ -213,6 +215,8 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.masks = h->masks;
   for (int d = 0; d < 3; d++) a.ms[d] = sizeof(T) == 4 ? (T)h->ms_f[d] : (T)(h->L[d] / h->m[d]);
   a.delta = (T)h->mfma_delta;
+  a.mf_scale = (T)h->mfma_scale, a.mf_scale2 = (T)(h->mfma_scale * h->mfma_scale);
+  a.delta16 = (T)(h->mfma_delta16 * h->mfma_scale * h->mfma_scale);
   a.pbc = h->pbc ? 1 : 0;
   for (int d = 0; d < 3; d++) a.L[d] = (T)h->L[d];
   a.z_origin = h->b_slab ? h->b_zlo - 1 : 0;
@@ -250,7 +254,10 @@ template <typename T, bool FULL> void launch_sweep_kind(nl_handle_t h, int mode,
       if constexpr (sizeof(T) == 4) {
         if constexpr (!FULL) {
           if (h->b_use_mfma) {
-            hipLaunchKernelGGL(k_sweep_mfma_f32, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
+            if (h->b_variant == 5)
+              hipLaunchKernelGGL(k_sweep_mfma_f16, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
+            else
+              hipLaunchKernelGGL(k_sweep_mfma_f32, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
             return;
           }
         }
@@ -262,15 +269,7 @@ template <typename T, bool FULL> void launch_sweep_kind(nl_handle_t h, int mode,
       if (h->n > 0)
         hipLaunchKernelGGL(k_row_base, dim3(nbp), dim3(256), 0, s, h->key_pointer, h->sorted_row, h->n_rows, h->n,
                            h->base_sorted);
-      if constexpr (!FULL) {
-        if (h->b_use_mfma) {
-          hipLaunchKernelGGL((k_fill_masks<T, MASK_TILE16>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
-                             h->base_sorted);
-          return;
-        }
-      }
-      hipLaunchKernelGGL((k_fill_masks<T, MASK_LANE64, FULL>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
-                         h->base_sorted);
+      hipLaunchKernelGGL((k_fill_masks<T, FULL>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
     }
     return;
   }
@@ -304,7 +303,7 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   // (the persistent and matrix-core variants implement the reference's open-box distances and the half list only)
   h->b_variant = (h->b_full || h->pbc) ? (h->sweep_variant >= 3 ? 3 : 1) : h->sweep_variant;
   h->b_use_masks = h->b_variant >= 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
-  h->b_use_mfma = h->b_use_masks && h->b_variant == 4 && sizeof(T) == 4;
+  h->b_use_mfma = h->b_use_masks && h->b_variant >= 4 && sizeof(T) == 4;
   const int32_t nbp = (n + 255) / 256;
   const T* q = static_cast<const T*>(q_dev);
 
@@ -486,6 +485,13 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     for (int d = 0; d < 3; d++) diag2 += (double)h->ms_f[d] * h->ms_f[d];
     const double S = (std::sqrt(diag2) + rc) * (std::sqrt(diag2) + rc);
     h->mfma_delta = (float)(S / 262144.0);
+    // f16 form: the two-piece split (top 11 bits + 11 truncated bits) represents a coordinate to 2^-21 relative, four
+    // times coarser than fp32: the same budget with that term four times larger stays below 2^-19.5 S; delta16 =
+    // 2^-17 S.  Scale: the largest power of two that keeps 2 max(ms) * scale <= 96, so that every particle of the
+    // 27 cells has |u|^2 scale^2 <= 3 * 72^2 < 60000 (the far-sentinel threshold, below the f16 maximum 65504).
+    h->mfma_delta16 = S / 131072.0;
+    const double umax = 2.0 * std::max(h->ms_f[0], std::max(h->ms_f[1], h->ms_f[2]));
+    h->mfma_scale = std::exp2(std::floor(std::log2(96.0 / umax)));
   }
   h->ncell = (int64_t)m[0] * m[1] * m[2];
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -502,7 +508,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
-    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(4, std::max(1, atoi(v)));
+    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(5, std::max(1, atoi(v)));
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_DEBUG_FLAGS")) h->dbg_flags = atoi(v);
     if (const char* v = getenv("NL_DEBUG_WG_PER_CU")) h->dbg_wg_per_cu = std::max(1, atoi(v));

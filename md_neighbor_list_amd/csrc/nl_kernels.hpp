@@ -530,6 +530,7 @@ template <typename T> struct SweepArgs {
                                   // at their image, coordinate -+ L (nl_set_periodic; not in the reference)
   T ms[3];                        // cell edge rounded to T (neighlist_cpu.hpp:404-406); k_sweep_mfma_f32 only
   T delta;                        // k_sweep_mfma_f32: |r2 - rc2| below this is re-tested exactly
+  T delta16, mf_scale, mf_scale2; // k_sweep_mfma_f16: the band in scaled units, the power-of-two scale and its square
   int32_t z_origin;               // global z layer of local layer 0
   uint32_t* __restrict__ masks;  // [n][64]: bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
@@ -841,26 +842,13 @@ __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan ov
 
 constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
 
-// Hit-word layouts.  MASK_LANE64 (search_group): 64 words per row, word l, bit t  <->  staged particle t*64 + l.
-// MASK_TILE16 (k_sweep_mfma_f32): 48 words per row, word g*16 + lam, bit 31 - b  <->  staged particle
-// (32 g + b)*16 + lam (16-particle tiles, 32 tiles per word group).
-enum { MASK_LANE64 = 0, MASK_TILE16 = 1 };
-constexpr int MASK16_WORDS = 48;
-constexpr int MASK16_MAX_ROWS = 64;  // cells with more rows have no masks on the TILE16 path (searched again by k_fill_masks)
-
-template <typename T, int LAYOUT, bool FULL = false>
+template <typename T, bool FULL = false>
 __global__ void __launch_bounds__(EXPAND_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
   constexpr int EW = EXPAND_WAVES;
   // 5 KiB: ids only, so many workgroups per CU keep enough loads in flight
-  // MASK_TILE16 keeps the ids permuted so that lane l always reads bank l (as LANE64 does by construction):
-  // staged particle (32 g + b)*16 + lam  ->  index b*64 + g*16 + lam, 32 x 64 entries
-  constexpr int NGID = LAYOUT == MASK_LANE64 ? CAP : (CAP > 2048 ? CAP : 2048);
-  __shared__ __attribute__((aligned(32))) int32_t gids[NGID];
-  auto gslot = [](int32_t p) {
-    return LAYOUT == MASK_LANE64 ? p : ((p >> 4) & 31) * 64 + (p >> 9) * 16 + (p & 15);
-  };
+  __shared__ __attribute__((aligned(32))) int32_t gids[CAP];
   if (a.total[0] > a.capacity) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
     return;
@@ -868,7 +856,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   CellCtx c;
   if (!cell_setup(a, lane, c)) return;
-  if (c.total_j > CAP || (LAYOUT == MASK_TILE16 && c.ni > MASK16_MAX_ROWS)) {
+  if (c.total_j > CAP) {
     // No masks for this cell (its stencil needed several LDS batches in COUNT_MASKS): search it again, as
     // k_sweep<FILL> does, in small batches through the id buffer.  Rare (very dense cells only).
     constexpr int CAPS = (int)(CAP * sizeof(int32_t) / (sizeof(Pos<T>))) / WAVE * WAVE;
@@ -888,10 +876,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const int32_t slot = c.ibeg + min(r0 + u, c.ni - 1);
-      if (LAYOUT == MASK_LANE64)
-        w[u] = a.masks[(size_t)slot * WAVE + lane];
-      else
-        w[u] = lane < MASK16_WORDS ? a.masks[(size_t)slot * MASK16_WORDS + lane] : 0u;
+      w[u] = a.masks[(size_t)slot * WAVE + lane];
       base[u] = base_sorted[slot];  // (k_row_base: one gather kernel is cheaper than two dependent loads here)
     }
   };
@@ -909,13 +894,12 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
       const bool p1 = k1 < len;
       const int32_t v0 = a.sorted[src + k].gid;
       const int32_t v1 = a.sorted[src + (p1 ? k1 : k)].gid;
-      gids[gslot(off + k)] = v0;
-      if (p1) gids[gslot(off + k1)] = v1;
+      gids[off + k] = v0;
+      if (p1) gids[off + k1] = v1;
     }
   }
   __syncthreads();  // ids staged
 
-  // lane -> address of the particle of its word's first bit (LANE64: lowest bit first; TILE16: highest bit first)
   const int32_t* const g = gids + lane;
   for (int32_t r0 = r_beg; r0 < r_end; r0 += RB) {
     if (r0 != r_beg) load_rows(r0);  // dense cells only
@@ -938,22 +922,15 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           on[q] = word[q] != 0;
-          // unconditional read of a valid slot: the four reads go out back to back
-          if (LAYOUT == MASK_LANE64) {
-            const int32_t t = on[q] ? __ffs(word[q]) - 1 : 0;
-            val[q] = g[t * WAVE];
-          } else {
-            const int32_t t = on[q] ? __clz(word[q]) : 0;
-            val[q] = g[t * WAVE];
-            if (on[q]) word[q] ^= 0x80000000u >> t;
-          }
+          const int32_t t = on[q] ? __ffs(word[q]) - 1 : 0;
+          val[q] = g[t * WAVE];  // unconditional read of a valid slot: the four reads go out back to back
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           if (on[q]) {
             *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + ((size_t)ptr[q] << 2)) = val[q];
             ptr[q]++;
-            if (LAYOUT == MASK_LANE64) word[q] &= word[q] - 1;
+            word[q] &= word[q] - 1;
           }
         }
       }

@@ -17,13 +17,13 @@
 // accumulator (sign = accepted), and one v_alignbit that shifts the sign bit into the lane's hit word.  No scalar bookkeeping per test: the counts are
 // popcounts of the hit words at the end.
 //
-// Work split: a workgroup of 6 waves owns an i-cell.  The stencil stream is staged ONCE into LDS as four component
-// arrays (ux, uy, uz, |u|^2) + ids (26 KB: five workgroups = 30 waves per CU).  A unit of work is one i-block (16
-// rows) against one half of the j-tiles (16 particles each): tiles [0, 32) or [32, ntiles); a cell of 33..48 rows has
-// six units, one per wave.  Little per-wave state (one MFMA accumulator pair, 4 row constants, 4 hit words).
-// Hit words (layout MASK_TILE16, 48 per row): word (t / 32)*16 + lam, bit 31 - t % 32 for tile t and lam = j % 16;
-// the halves meet at a word boundary, so every word has one writer and goes straight to memory in 64-byte pieces.
-// k_fill_masks<T, MASK_TILE16> expands them.
+// Work split: a workgroup of 4 waves owns an i-cell.  The stencil stream is staged ONCE into LDS as four component
+// arrays (ux, uy, uz, |u|^2) + ids (26 KB: six workgroups = 24 waves per CU).  A unit of work is one i-block (16
+// rows) against the tiles (16 staged particles each) of one residue class t = w (mod 4); wave w walks the i-blocks
+// with residue w, so the four waves -- one per SIMD -- do the same number of steps.  Little per-wave state (one MFMA
+// accumulator pair, 4 row constants, 4 hit words).
+// Hit words: step s of residue w tests staged particle s*64 + (w*16 + lam), which is bit s of word w*16 + lam of the
+// mask layout search_group writes: k_fill_masks expands both alike, and the units own 16 words each (64-byte stores).
 #pragma once
 
 namespace nl {
@@ -33,9 +33,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MF_CAP = SweepCfg<float>::CAP;  // staged particles per cell: the same single-batch limit as the masks
 constexpr int MF_CSTR = MF_CAP + 16;          // component array stride: the four bases fall on banks 0, 16, 32, 48
 constexpr int MF_TILE = 16;
-constexpr int MF_WAVES = 6;                   // waves per workgroup
-constexpr int MF_ROWS = 64;                   // most rows a cell may have on this path (k_fill_masks knows this too)
-constexpr int MF_WORDS = (MF_CAP / MF_TILE + 31) / 32 * 16;  // hit words per row: 3 groups of 32 tiles x 16 lanes = 48
+constexpr int MF_WAVES = 4;                   // waves per workgroup: wave w takes the tiles t = w (mod 4)
+constexpr int MF_ROWS = 64;                   // most rows of a cell on this path (LDS row counters); fuller cells take
+                                              // the VALU search, which writes the same masks
 
 struct MfmaLds {
   float comp[4 * MF_CSTR];  // ux | uy | uz | |u|^2 of the staged stream
@@ -43,7 +43,7 @@ struct MfmaLds {
   int32_t cnt[MF_ROWS];
 };
 static_assert(sizeof(float) * 4 * MF_CSTR >= sizeof(Pos<float>) * SweepCfg<float>::CAP, "fallback tile fits");
-static_assert(MF_WORDS == MASK16_WORDS && MF_WORDS == 48 && MF_ROWS == MASK16_MAX_ROWS, "layout shared with k_fill_masks");
+static_assert(MF_CAP / MF_TILE / 4 <= 32, "a unit's steps fit one hit word");
 
 // stream position -> index in the sorted array (walks the 18-entry segment table held one entry per lane)
 __device__ __forceinline__ int32_t mf_stream_to_sorted(const CellCtx& c, int32_t p) {
@@ -62,32 +62,87 @@ __device__ __forceinline__ int32_t mf_stream_to_sorted(const CellCtx& c, int32_t
 #define MF_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x4f32(A_, B_, C_, 0, 0, 0)
 #endif
 
-// One unit: the i-block of 16 rows starting at row i0 of the cell against half `half` of the ntiles staged tiles.
+// ---- the f16 form (NL_SWEEP_VARIANT=5).  The fp32 MFMA runs at the vector rate and holds the SIMD's vector issue
+// for its 32 cycles; v_mfma_f32_16x16x32_f16 takes 8.  An fp32 value v (scaled by a power of two so that |v| < 2^7
+// for everything near the cell) is carried as two halves, h = v with its low 13 mantissa bits cleared and
+// l = rtz_f16(v - h): products of halves are exact in the fp32 accumulator, and h + l differs from v by < 2^-21 |v|.
+// With K = 32 one instruction holds, per coordinate, the four products (-2 h_i)(h_j), (-2 h_i)(l_j), (-2 l_i)(h_j),
+// (-2 l_i)(l_j), and 1 * (|u_j|^2 as two halves); lanes 16 q .. 16 q + 15 carry k = 8 q .. 8 q + 7 (q = x, y, z, norm).
+// The B operand of a lane is {(h_j, l_j), (h_j, l_j), 0, 0}: one packed dword per staged particle and component, as
+// in the fp32 form.  Decisive values only, the same band logic (delta is widened by the host for the coarser split).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t mf_split16(float v) {  // (h, l) packed: h in the low half
+  const float h = __uint_as_float(__float_as_uint(v) & 0xFFFFE000u);
+  typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+  const fp16x2 p = __builtin_amdgcn_cvt_pkrtz(h, v - h);
+  return __builtin_bit_cast(uint32_t, p);
+}
+__device__ __forceinline__ float mf_join16(uint32_t p) {  // h + l back as fp32
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  const f16x2 v = __builtin_bit_cast(f16x2, p);
+  return (float)v[0] + (float)v[1];
+}
+
+// One unit: the i-block of 16 rows starting at row i0 of the cell against the tiles t = res (mod 4) of the ntiles
+// staged tiles.
 // i_off: stream position of the cell's own first particle (the i-particles are part of their own stencil, so their
 // local coordinates and ids are already in LDS).
+template <bool F16 = false>
 __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx& c, MfmaLds& L, int lane,
-                                        int32_t i_off, int32_t i0, int32_t half, int32_t ntiles) {
+                                        int32_t i_off, int32_t i0, int32_t res, int32_t ntiles) {
   const int kq = lane >> 4, lam = lane & 15;
-  float A;
+  float A = 0.f;      // fp32 form: one value of the 16 x 4 operand
+  f16x8 A16 = {};     // f16 form: eight halves of the 16 x 32 operand
   f32x4 C;
   int32_t gi[4];
   {
     const int32_t irow = i0 + lam;
     const float u = L.comp[min(kq, 2) * MF_CSTR + i_off + min(irow, c.ni - 1)];
-    A = irow < c.ni ? (kq == 3 ? 1.0f : mul_rn(-2.0f, u)) : 0.0f;
+    if constexpr (!F16) {
+      A = irow < c.ni ? (kq == 3 ? 1.0f : mul_rn(-2.0f, u)) : 0.0f;
+    } else {
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      const f16x2 hl = __builtin_bit_cast(f16x2, __float_as_uint(u));  // (h, l) of this coordinate
+      const _Float16 m2 = (_Float16)-2.0f, one = (_Float16)1.0f, zero = (_Float16)0.0f;
+      const _Float16 a_h = kq == 3 ? one : m2 * hl[0], a_l = kq == 3 ? zero : m2 * hl[1];
+      if (irow < c.ni) A16 = f16x8{a_h, a_h, a_l, a_l, zero, zero, zero, zero};
+    }
   }
+  const float rc2s = F16 ? a.rc2 * a.mf_scale2 : a.rc2;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int32_t irow = i0 + 4 * kq + r;
     const int32_t p = i_off + min(irow, c.ni - 1);
-    C[r] = irow < c.ni ? sub_rn(L.comp[3 * MF_CSTR + p], a.rc2) : 1.0e30f;  // padding rows: never accepted
+    const float n2 = F16 ? mf_join16(__float_as_uint(L.comp[3 * MF_CSTR + p])) : L.comp[3 * MF_CSTR + p];
+    C[r] = irow < c.ni ? sub_rn(n2, rc2s) : 1.0e30f;  // padding rows: never accepted
     gi[r] = L.gid[p];
   }
 
   const float* const bp = L.comp + kq * MF_CSTR + lam;
   const int32_t* const gp = L.gid + lam;
-  const float delta = a.delta;
+  const float delta = F16 ? a.delta16 : a.delta;
   uint32_t bits[4];
+  // acc = MFMA(A, staged dword, C)
+  auto mma = [&](float bv) -> f32x4 {
+    if constexpr (!F16) {
+      return MF_MFMA(A, bv, C);
+    } else {
+      // Written as assembly for its VGPR form: through the builtin this compiler allocates the accumulator in AGPRs
+      // (4 v_accvgpr_read per step and one accumulator for both tiles of the ping-pong).  The compiler does not
+      // see the MFMA -> VALU read hazard of an asm statement; the reads of the result come a whole process() of the
+      // OTHER tile later (>= 16 vector instructions behind a branch, i.e. a block boundary), far more than the 4
+      // passes the instruction takes.  The other hazard is on the way in: the B tuple is assembled by v_mov right
+      // before, and an MFMA must not read a VGPR a VALU instruction has just written -- hence the s_nop (without
+      // it the kernel produced wrong lists; 5 wait states verified).
+      const uint32_t w = __float_as_uint(bv);
+      const u32x4 b4 = {w, w, 0u, 0u};
+      f32x4 d;
+      asm volatile("s_nop 4\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(A16), "v"(b4), "v"(C));
+      return d;
+    }
+  };
 
   // One tile's accumulators -> one more bit in every hit word.
   auto process = [&](const f32x4& acc, int32_t gj, int32_t t) {
@@ -130,53 +185,45 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
     }
   };
 
-  // Word group g = tiles [32 g, 32 g + n): search them into `bits` (nothing to do for n <= 0), store the group's
-  // words of the block's rows, add their popcounts to `total`.
-  int32_t total[4] = {0, 0, 0, 0};
-  auto run = [&](int32_t g, int32_t n) {
+  // The unit's tiles are t = res, res + 4, res + 8, ...: step s tests the 16 staged particles (res + 4 s)*16 + lam,
+  // i.e. particle s*64 + (res*16 + lam) -- word res*16 + lam, bit s of the LANE64 mask layout that k_fill_masks
+  // expands (search_group writes the same words): the four units of an i-block own 16 words each.
+  const int32_t ns = a.dbg & 1 ? 0 : (ntiles - res + 3) >> 2;  // steps of this unit (<= 20)
 #pragma unroll
-    for (int r = 0; r < 4; r++) bits[r] = 0;
-    if (n > 0) {
-      const int32_t tb = 32 * g, t_last = tb + n - 1;
-      // Two accumulators in ping-pong: the MFMA of the next tile is issued before the vector work of the current
-      // one.  Tile indices beyond the run are clamped (the result of such an MFMA is never consumed).
+  for (int r = 0; r < 4; r++) bits[r] = 0;
+  if (ns > 0) {
+    const int32_t s_last = ns - 1;
+    // Two accumulators in ping-pong: the MFMA of the next step is issued before the vector work of the current
+    // one.  Steps beyond the last are clamped (the result of such an MFMA is never consumed).
 #ifdef MF_ABL_NO_LDS  // ablation: every step reads the same tile (the loads are hoisted out of the loop)
-      auto tix = [&](int32_t) { return tb * MF_TILE; };
+    auto tix = [&](int32_t) { return res * MF_TILE; };
 #else
-      auto tix = [&](int32_t t) { return min(t, t_last) * MF_TILE; };
+    auto tix = [&](int32_t s_) { return (res + 4 * min(s_, s_last)) * MF_TILE; };
 #endif
-      float bv0 = bp[tix(tb)], bv1 = bp[tix(tb + 1)];
-      int32_t g0 = gp[tix(tb)], g1 = gp[tix(tb + 1)];
-      f32x4 acc0 = MF_MFMA(A, bv0, C), acc1;
-      for (int32_t t = tb; t <= t_last; t += 2) {
-        acc1 = MF_MFMA(A, bv1, C);
-        bv0 = bp[tix(t + 2)];
-        const int32_t g0n = gp[tix(t + 2)];
-        process(acc0, g0, t);
-        acc0 = MF_MFMA(A, bv0, C);
-        bv1 = bp[tix(t + 3)];
-        const int32_t g1n = gp[tix(t + 3)];
-        if (t + 1 <= t_last) process(acc1, g1, t + 1);
-        g0 = g0n, g1 = g1n;
-      }
-      const uint32_t up = 32u - (uint32_t)n;  // first tile of the group -> bit 31
-#pragma unroll
-      for (int r = 0; r < 4; r++) bits[r] <<= up;
+    float bv0 = bp[tix(0)], bv1 = bp[tix(1)];
+    int32_t g0 = gp[tix(0)], g1 = gp[tix(1)];
+    f32x4 acc0 = mma(bv0), acc1;
+    for (int32_t s_ = 0; s_ <= s_last; s_ += 2) {
+      acc1 = mma(bv1);
+      bv0 = bp[tix(s_ + 2)];
+      const int32_t g0n = gp[tix(s_ + 2)];
+      process(acc0, g0, res + 4 * s_);
+      acc0 = mma(bv0);
+      bv1 = bp[tix(s_ + 3)];
+      const int32_t g1n = gp[tix(s_ + 3)];
+      if (s_ + 1 <= s_last) process(acc1, g1, res + 4 * (s_ + 1));
+      g0 = g0n, g1 = g1n;
     }
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int32_t irow = i0 + 4 * kq + r;
-#ifndef MF_ABL_NO_STORE
-      if (irow < c.ni) a.masks[(size_t)(c.ibeg + irow) * MF_WORDS + g * 16 + lam] = bits[r];
-#endif
-      total[r] += __popc(bits[r]);
-    }
-  };
-  // half 0: word group 0; half 1: word groups 1 and 2 (one instance of the loop body for all three)
-  for (int32_t g = half; g < 1 + 2 * half; g++) run(g, a.dbg & 1 ? 0 : min(32, ntiles - 32 * g));
+  }
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    int32_t v = total[r];
+    const int32_t irow = i0 + 4 * kq + r;
+    // step s sits at bit ns - 1 - s (v_alignbit shifts left): reverse into bit s
+    const uint32_t w = ns > 0 ? __brev(bits[r]) >> (32 - ns) : 0u;
+#ifndef MF_ABL_NO_STORE
+    if (irow < c.ni) a.masks[(size_t)(c.ibeg + irow) * WAVE + res * 16 + lam] = w;
+#endif
+    int32_t v = __popc(w);
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1 within the 16 lanes of a row group
     v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
     v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
@@ -196,7 +243,8 @@ __device__ __forceinline__ void mf_stamp(const SweepArgs<float>& a, int tid, int
   }
 }
 
-__global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f32(SweepArgs<float> a) {
+template <bool F16>
+__device__ __forceinline__ void mf_cell(const SweepArgs<float>& a) {
   __shared__ __attribute__((aligned(16))) MfmaLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned long long t_prev = 0;
@@ -205,10 +253,10 @@ __global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f32(SweepArgs<
   if (!cell_setup(a, lane, c)) return;
   mf_stamp(a, tid, 0, t_prev);  // cell table
   if (c.total_j > MF_CAP || c.ni > MF_ROWS) {
-    // stencil larger than one LDS batch (or a very full cell): counts only, by the VALU search; k_fill_masks
-    // searches such cells again
-    cell_search<float, MODE_COUNT, SweepCfg<float>::CAP, MF_WAVES>(a, c, reinterpret_cast<Pos<float>*>(L.comp), tid, lane,
-                                                                   wave);
+    // stencil larger than one LDS batch, or a very full cell: the VALU search (same masks, same counts; cells of
+    // several batches get counts only and are searched again by k_fill_masks)
+    cell_search<float, MODE_COUNT_MASKS, SweepCfg<float>::CAP, MF_WAVES>(a, c, reinterpret_cast<Pos<float>*>(L.comp), tid,
+                                                                         lane, wave);
     return;
   }
   // centre of the i-cell: the origin of the local coordinates (any point near the cell would do)
@@ -227,10 +275,25 @@ __global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f32(SweepArgs<
   // ---- stage the stream as component arrays.  Wave w copies segments w, w + 6, w + 12; the loads of the first
   // 192 particles of each are all issued before the first LDS write (one memory round trip per cell, not one
   // per 128 particles); longer segments (dense cells) finish in a plain loop.
+  // the far sentinel of the f16 form: |u|^2 = 60000 (as halves), coordinates 0: acc = c_i + 60000 > 0 for every row
+  const uint32_t far16 = mf_split16(60000.0f);
   auto put = [&](int32_t p, const Pos<float>& v) {
-    const float ux = sub_rn(v.x, ccx), uy = sub_rn(v.y, ccy), uz = sub_rn(v.z, ccz);
-    L.comp[p] = ux, L.comp[MF_CSTR + p] = uy, L.comp[2 * MF_CSTR + p] = uz;
-    L.comp[3 * MF_CSTR + p] = add_rn(add_rn(mul_rn(ux, ux), mul_rn(uy, uy)), mul_rn(uz, uz));
+    float ux = sub_rn(v.x, ccx), uy = sub_rn(v.y, ccy), uz = sub_rn(v.z, ccz);
+    if constexpr (!F16) {
+      L.comp[p] = ux, L.comp[MF_CSTR + p] = uy, L.comp[2 * MF_CSTR + p] = uz;
+      L.comp[3 * MF_CSTR + p] = add_rn(add_rn(mul_rn(ux, ux), mul_rn(uy, uy)), mul_rn(uz, uz));
+    } else {
+      ux *= a.mf_scale, uy *= a.mf_scale, uz *= a.mf_scale;  // power of two: exact
+      const float n2 = add_rn(add_rn(mul_rn(ux, ux), mul_rn(uy, uy)), mul_rn(uz, uz));
+      // a particle this far from the cell centre (|u| scale >= 245, against <= 42 for the cell's own particles and
+      // rc scale <= 48) cannot be within the cut-off of any row near the centre; its halves would overflow: it
+      // becomes a far sentinel.  (Rows that are themselves far from the centre: see the check after the barrier.)
+      const bool far = !(n2 < 60000.0f);
+      L.comp[p] = __uint_as_float(far ? 0u : mf_split16(ux));
+      L.comp[MF_CSTR + p] = __uint_as_float(far ? 0u : mf_split16(uy));
+      L.comp[2 * MF_CSTR + p] = __uint_as_float(far ? 0u : mf_split16(uz));
+      L.comp[3 * MF_CSTR + p] = __uint_as_float(far ? far16 : mf_split16(n2));
+    }
     L.gid[p] = v.gid;
   };
   if (!(a.dbg & 2)) {
@@ -259,7 +322,7 @@ __global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f32(SweepArgs<
     const int32_t pad = c.total_j + tid;
     if (pad < ((c.total_j + MF_TILE - 1) & ~(MF_TILE - 1))) {
       L.comp[pad] = 0.f, L.comp[MF_CSTR + pad] = 0.f, L.comp[2 * MF_CSTR + pad] = 0.f;
-      L.comp[3 * MF_CSTR + pad] = 1.0e30f;
+      L.comp[3 * MF_CSTR + pad] = F16 ? __uint_as_float(far16) : 1.0e30f;
       L.gid[pad] = 0;
     }
   }
@@ -269,13 +332,31 @@ __global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f32(SweepArgs<
   mf_stamp(a, tid, 2, t_prev);  // barrier
 
   const int32_t ntiles = (c.total_j + MF_TILE - 1) / MF_TILE;
-  const int32_t nunits = 2 * ((c.ni + 15) >> 4);
-  for (int32_t u = wave; u < nunits; u += MF_WAVES) mf_unit(a, c, L, lane, i_off, (u >> 1) * 16, u & 1, ntiles);
+  if constexpr (F16) {
+    // A particle can lie far from the cell it is filed in: a coordinate that rounds up to the box edge is wrapped to
+    // cell 0 (GenHash + ApplyPBC, neighlist_cpu.hpp:51-66), coordinates up to one box length outside are legal.
+    // As a j-particle such a one is a far sentinel, which is right for every row near the cell centre; as a ROW it
+    // needs the real arithmetic: a cell that owns one is searched by the VALU path (same masks, same counts).
+    // Every wave tests all rows itself, so the decision is uniform without another barrier.
+    const bool row_far = lane < c.ni && mf_join16(__float_as_uint(L.comp[3 * MF_CSTR + i_off + lane])) >= 30000.0f;
+    if (__builtin_amdgcn_ballot_w64(row_far) != 0) {
+      __syncthreads();  // (rare) everyone has read its rows before the stream is staged again as positions
+      cell_search<float, MODE_COUNT_MASKS, SweepCfg<float>::CAP, MF_WAVES>(a, c, reinterpret_cast<Pos<float>*>(L.comp),
+                                                                           tid, lane, wave);
+      return;
+    }
+  }
+  // one unit per (i-block, tile residue): wave w walks the i-blocks with residue w -- every wave of the workgroup
+  // (one per SIMD) does the same number of steps
+  for (int32_t i0 = 0; i0 < c.ni; i0 += 16) mf_unit<F16>(a, c, L, lane, i_off, i0, wave, ntiles);
   mf_stamp(a, tid, 3, t_prev);  // search + word stores
   __syncthreads();
   mf_stamp(a, tid, 4, t_prev);  // barrier
   if (tid < c.ni) a.count[a.sorted_row[c.ibeg + tid]] = L.cnt[tid];
   mf_stamp(a, tid, 5, t_prev);  // counts
 }
+
+__global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f32(SweepArgs<float> a) { mf_cell<false>(a); }
+__global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f16(SweepArgs<float> a) { mf_cell<true>(a); }
 
 }  // namespace nl

@@ -209,10 +209,10 @@ def test_baseline_sizes_known_answers(key):
         assert np.array_equal(np.sort(sl[kp[i]:kp[i + 1]]), want.astype(np.int32))
 
 
-@pytest.mark.parametrize("variant,binning", [(1, 0), (2, 0), (3, 0), (4, 0), (4, 1), (1, 1)])
+@pytest.mark.parametrize("variant,binning", [(1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (4, 1), (1, 1)])
 def test_every_sweep_variant_and_binning_path(variant, binning, monkeypatch):
     """The non-default kernels stay correct: NL_SWEEP_VARIANT 1 (COUNT + FILL sweeps), 2 (persistent LDS-DMA),
-    3 (VALU hit masks, default), 4 (matrix-core hit masks); NL_BINNING=1 (atomic-rank hash/reorder)."""
+    3 (VALU hit masks, default), 4 / 5 (matrix-core hit masks, fp32 / f16 two-piece); NL_BINNING=1 (atomic-rank hash/reorder)."""
     monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
     monkeypatch.setenv("NL_BINNING", str(binning))
     for n, box, rc, seed in [(50000, (36.84, 36.84, 36.84), 3.3, 41), (9000, (25.0, 14.0, 19.0), 3.1, 42)]:
@@ -225,10 +225,10 @@ def test_every_sweep_variant_and_binning_path(variant, binning, monkeypatch):
         assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 5])
 def test_pairs_at_the_cutoff_fp32(variant, monkeypatch):
     """Partners placed at distance rc*(1 +- k ulp) around random centres: every one of them falls inside the band
-    that the matrix-core search (k_sweep_mfma_f32, variant 4) must re-test with the reference's exact fp32
+    that the matrix-core searches (k_sweep_mfma_f32 / _f16, variants 4 / 5) must re-test with the reference's exact fp32
     expression; variant 3 tests them with that expression directly."""
     monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
     rng = np.random.default_rng(77)
@@ -364,7 +364,7 @@ def test_random_small_boxes_against_oracle():
             assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), case
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 5])
 def test_random_mask_pipeline_boxes_against_oracle(variant, monkeypatch):
     """Twelve seeded random problems large enough for the hit-mask pipelines (VALU masks, matrix-core masks):
     non-cubic boxes of 5..10 cells per axis with 15..38 particles per cell."""
@@ -379,7 +379,7 @@ def test_random_mask_pipeline_boxes_against_oracle(variant, monkeypatch):
         ref = _po().build(q, rc, box)
         nl, nop, kp, sl = gpu_build(q, rc, box)
         info = nl.build_info()
-        assert info["masks"] and info["mfma"] == (variant == 4), (case, info)
+        assert info["masks"] and info["mfma"] == (variant >= 4), (case, info)
         assert int(kp[-1]) == ref.npairs, case
         assert np.array_equal(nop, ref.number_of_partners), case
         assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), case

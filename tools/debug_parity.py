@@ -6,7 +6,10 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from md_neighbor_list_amd import inputs  # noqa: E402
+from md_neighbor_list_amd import inputs, _lib  # noqa: E402
+
+if os.environ.get("NL_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["NL_LIB"])
 from oracle import pyoracle as po  # noqa: E402
 from tests.util import canonical_csr, gpu_build  # noqa: E402
 

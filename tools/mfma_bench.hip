@@ -25,7 +25,7 @@ using namespace nl;
 
 constexpr int NJ = 1056, NI = 40, IOFF = 512;
 
-template <int NI>
+template <int NI, bool F16>
 __global__ void __launch_bounds__(MF_WAVES * 64, 8) kb(SweepArgs<float> a, int reps, unsigned long long* stamps, uint32_t* sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
   MfmaLds& L = *reinterpret_cast<MfmaLds*>(raw);
@@ -33,9 +33,16 @@ __global__ void __launch_bounds__(MF_WAVES * 64, 8) kb(SweepArgs<float> a, int r
   const float cc = 1.5f * 3.386f;
   for (int k = tid; k < NJ; k += MF_WAVES * 64) {
     const Pos<float> v = a.sorted[k];
-    const float ux = v.x - cc, uy = v.y - cc, uz = v.z - cc;
-    L.comp[k] = ux, L.comp[MF_CSTR + k] = uy, L.comp[2 * MF_CSTR + k] = uz;
-    L.comp[3 * MF_CSTR + k] = ux * ux + uy * uy + uz * uz;
+    float ux = v.x - cc, uy = v.y - cc, uz = v.z - cc;
+    if (F16) {
+      ux *= a.mf_scale, uy *= a.mf_scale, uz *= a.mf_scale;
+      L.comp[k] = __uint_as_float(mf_split16(ux)), L.comp[MF_CSTR + k] = __uint_as_float(mf_split16(uy));
+      L.comp[2 * MF_CSTR + k] = __uint_as_float(mf_split16(uz));
+      L.comp[3 * MF_CSTR + k] = __uint_as_float(mf_split16(ux * ux + uy * uy + uz * uz));
+    } else {
+      L.comp[k] = ux, L.comp[MF_CSTR + k] = uy, L.comp[2 * MF_CSTR + k] = uz;
+      L.comp[3 * MF_CSTR + k] = ux * ux + uy * uy + uz * uz;
+    }
     L.gid[k] = v.gid;
   }
   if (tid < MF_ROWS) L.cnt[tid] = 0;
@@ -44,34 +51,34 @@ __global__ void __launch_bounds__(MF_WAVES * 64, 8) kb(SweepArgs<float> a, int r
   CellCtx c{};
   c.ibeg = IOFF, c.ni = NI, c.total_j = NJ;
   c.seg_src = 0, c.seg_len = lane == 0 ? NJ : 0, c.seg_off = lane == 0 ? 0 : NJ;
-  const int32_t ntiles = NJ / 16, nunits = 2 * ((NI + 15) / 16);
+  const int32_t ntiles = NJ / 16;
   unsigned long long t0, t1;
   asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
   for (int r = 0; r < reps; r++)
-    for (int32_t u = wave; u < nunits; u += MF_WAVES) mf_unit(a, c, L, lane, IOFF, (u >> 1) * 16, u & 1, ntiles);
+    for (int32_t i0 = 0; i0 < NI; i0 += 16) mf_unit<F16>(a, c, L, lane, IOFF, i0, wave, ntiles);
   asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
   if (lane == 0) stamps[blockIdx.x * MF_WAVES + wave] = t1 - t0;
   if (L.cnt[tid & 63] == 0x12345678) sink[0] = 1;
 }
 
-template <int NI> int run(const char* name, SweepArgs<float> a, unsigned long long* stamps_d, uint32_t* sink) {
+template <int NI, bool F16> int run(const char* name, SweepArgs<float> a, unsigned long long* stamps_d, uint32_t* sink) {
   hipDeviceProp_t prop;
   CHK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount, reps = 40;
-  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kb<NI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kb<NI, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   printf("%-12s", name);
-  for (int bpc : {1, 2, 3, 4, 5}) {
+  for (int bpc : {1, 2, 4, 6}) {
     const size_t lds = (size_t)(160 * 1024 / bpc) & ~(size_t)1023;
     const int blocks = cus * bpc, nw = blocks * MF_WAVES;
-    hipLaunchKernelGGL((kb<NI>), dim3(blocks), dim3(MF_WAVES * 64), lds, 0, a, 2, stamps_d, sink);
-    hipLaunchKernelGGL((kb<NI>), dim3(blocks), dim3(MF_WAVES * 64), lds, 0, a, reps, stamps_d, sink);
+    hipLaunchKernelGGL((kb<NI, F16>), dim3(blocks), dim3(MF_WAVES * 64), lds, 0, a, 2, stamps_d, sink);
+    hipLaunchKernelGGL((kb<NI, F16>), dim3(blocks), dim3(MF_WAVES * 64), lds, 0, a, reps, stamps_d, sink);
     CHK(hipDeviceSynchronize());
     std::vector<unsigned long long> st(nw);
     CHK(hipMemcpy(st.data(), stamps_d, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost));
     std::sort(st.begin(), st.end());
     // MFMA steps (one 16 x 16 block of tests) per SIMD: workgroups per CU x i-blocks x 66 tiles / 4 SIMDs
     const double steps = (double)reps * bpc * ((NI + 15) / 16) * (NJ / 16) / 4.0;
-    printf(" | %d wg/CU (%.1f waves/SIMD) max %6.1f", bpc, MF_WAVES * bpc / 4.0, (double)st[nw - 1] / steps);
+    printf(" | %d wg/CU (%d waves/SIMD) max %6.1f", bpc, bpc, (double)st[nw - 1] / steps);
   }
   printf("\n");
   return 0;
@@ -94,12 +101,14 @@ int main() {
   SweepArgs<float> a{};
   a.sorted = dj;
   uint32_t* masks;
-  CHK(hipMalloc(&masks, sizeof(uint32_t) * MF_WORDS * (IOFF + MF_ROWS)));
+  CHK(hipMalloc(&masks, sizeof(uint32_t) * 64 * (IOFF + MF_ROWS)));
   a.masks = masks;  // (every workgroup writes the same rows: timing only)
   a.rc2 = 3.3f * 3.3f;
   a.delta = 3.5e-4f;
   printf("mf_unit alone: shader cycles per SIMD per MFMA step (one 16 x 16 block of tests: 1 MFMA + its vector work),\nlast wave to finish\n");
-  run<40>("40 rows", a, stamps, sink);
-  run<64>("64 rows", a, stamps, sink);
+  a.mf_scale = 8.f, a.mf_scale2 = 64.f, a.delta16 = a.delta * 64.f;
+  run<40, false>("fp32, 40 rows", a, stamps, sink);
+  run<40, true>("f16,  40 rows", a, stamps, sink);
+  run<64, true>("f16,  64 rows", a, stamps, sink);
   return 0;
 }

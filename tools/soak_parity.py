@@ -17,13 +17,13 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 bad = 0
 for case in range(cases):
     dtype = np.float32 if rng.random() < 0.6 else np.float64
-    os.environ["NL_SWEEP_VARIANT"] = str(rng.integers(1, 5))
+    os.environ["NL_SWEEP_VARIANT"] = os.environ.get("SOAK_VARIANT") or str(rng.integers(1, 6))
     os.environ["NL_BINNING"] = str(rng.integers(0, 2))
     rc = float(rng.uniform(0.5, 5.0))
     mesh = rng.integers(3, 14, size=3)
     box = tuple(float(m * rc * rng.uniform(1.0, 1.3)) for m in mesh)
     ncell = int(mesh[0]) * int(mesh[1]) * int(mesh[2])
-    n = int(min(120000, max(1, ncell * rng.uniform(0.05, 60.0))))
+    n = int(min(120000, max(1, ncell * rng.uniform(*((10.0, 45.0) if os.environ.get("SOAK_VARIANT") else (0.05, 60.0))))))
     q = np.zeros((n, 4), dtype=dtype)
     q[:, :3] = rng.uniform(0.0, 1.0, size=(n, 3)) * np.array(box)
     q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=dtype), dtype(0)))
