@@ -30,8 +30,10 @@ namespace nl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MF_CAP = SweepCfg<float>::CAP;  // staged particles per cell: the same single-batch limit as the masks
-constexpr int MF_CSTR = MF_CAP + 16;          // component array stride: the four bases fall on banks 0, 16, 32, 48
+constexpr int MF_CAP = 1152;                  // staged particles per cell on this path (18 x 64); longer streams (one
+                                              // cell in 1500 at rho = 1) take the VALU search
+constexpr int MF_PAD = 144;                   // the operand fetch runs up to two steps (8 tiles) past the last tile
+constexpr int MF_CSTR = MF_CAP + MF_PAD;      // component array stride: the four bases fall on banks 0, 16, 32, 48
 constexpr int MF_TILE = 16;
 constexpr int MF_WAVES = 4;                   // waves per workgroup: wave w takes the tiles t = w (mod 4)
 constexpr int MF_ROWS = 64;                   // most rows of a cell on this path (LDS row counters); fuller cells take
@@ -39,11 +41,11 @@ constexpr int MF_ROWS = 64;                   // most rows of a cell on this pat
 
 struct MfmaLds {
   float comp[4 * MF_CSTR];  // ux | uy | uz | |u|^2 of the staged stream
-  int32_t gid[MF_CAP];
+  int32_t gid[MF_CSTR];
   int32_t cnt[MF_ROWS];
 };
 static_assert(sizeof(float) * 4 * MF_CSTR >= sizeof(Pos<float>) * SweepCfg<float>::CAP, "fallback tile fits");
-static_assert(MF_CAP / MF_TILE / 4 <= 32, "a unit's steps fit one hit word");
+static_assert(MF_CAP / MF_TILE / 4 <= 32 && MF_CSTR % 64 == 16 && MF_CAP <= SweepCfg<float>::CAP, "layout");
 
 // stream position -> index in the sorted array (walks the 18-entry segment table held one entry per lane)
 __device__ __forceinline__ int32_t mf_stream_to_sorted(const CellCtx& c, int32_t p) {
@@ -54,6 +56,17 @@ __device__ __forceinline__ int32_t mf_stream_to_sorted(const CellCtx& c, int32_t
     if (p >= off && p < off + len) idx = src + (p - off);
   }
   return idx;
+}
+
+// A 16-byte load that the compiler does not see as a pending memory operation (the wait is inside).  Used on the
+// rare exact re-test only: with ordinary loads there the compiler guards the step loop's head with s_waitcnt
+// vmcnt(0), which makes every unit wait for the hit-word STORES of the previous one.
+__device__ __forceinline__ Pos<float> mf_load_pos_blocking(const Pos<float>* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  Pos<float> r;
+  r.x = v[0], r.y = v[1], r.z = v[2], r.gid = (int32_t)__float_as_uint(v[3]);
+  return r;
 }
 
 #ifdef MF_ABL_NO_MFMA  // ablation: the vector work on an accumulator that no MFMA produces (bv keeps the loads alive)
@@ -144,10 +157,9 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
     }
   };
 
-  // One tile's accumulators -> one more bit in every hit word.
-  auto process = [&](const f32x4& acc, int32_t gj, int32_t t) {
-    // smallest |r2 - rc2| of the tile in this lane: v_min3_f32 with |.| source modifiers, half an instruction per value
-    float m = __builtin_huge_valf();
+  // One tile's accumulators -> one more bit in every hit word; returns the smallest |r2 - rc2| this lane saw
+  // (v_min3_f32 with |.| source modifiers: half an instruction per value).
+  auto process = [&](const f32x4& acc, int32_t gj, float m) {
 #pragma unroll
     for (int r = 0; r < 4; r++) m = __builtin_fminf(m, __builtin_fabsf(acc[r]));
     // sign(acc) = accepted by distance, sign(gid_i - gid_j) = j is the upper index (ids are >= 0)
@@ -157,62 +169,65 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
       const uint32_t h = __float_as_uint(av) & (uint32_t)(gi[r] - gj);
       bits[r] = __builtin_amdgcn_alignbit(bits[r], h, 31);  // (bits << 1) | (h >> 31)
     }
-#ifdef MF_ABL_NO_UNC  // tools/mfma_bench ablation: no band check at all (timing only, results wrong)
-    if (false) {
-#else
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m < delta) != 0, 0)) {
-#endif
-      // rare (about 1 % of the tiles): some |r2 - rc2| is inside the error band of the matrix-core expression.
-      // Re-test those elements with the reference's expression on the original coordinates and flip the bit just
-      // written where the exact answer differs.  (Nothing here writes the accumulators: the common path keeps them
-      // where the MFMA left them, without copies.)
-      const int32_t pj_pos = t * MF_TILE + lam;
-      const bool jok = pj_pos < c.total_j;
-      const Pos<float> pj = a.sorted[jok ? mf_stream_to_sorted(c, pj_pos) : c.ibeg];
+    return m;
+  };
+  // Rare (about 2 % of the step pairs): some |r2 - rc2| of tile t was inside the error band of the matrix-core
+  // expression.  The tile's 16 x 16 block is decided again from the original coordinates with the reference's
+  // expression and its bit (position `pos` of the words by now) rewritten.  Nothing here touches the accumulators.
+  auto retest = [&](int32_t t, int32_t gj, uint32_t pos) {
+    const int32_t pj_pos = t * MF_TILE + lam;
+    const bool jok = pj_pos < c.total_j;
+    const Pos<float> pj = mf_load_pos_blocking(a.sorted + (jok ? mf_stream_to_sorted(c, pj_pos) : c.ibeg));
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int32_t irow = i0 + 4 * kq + r;
-        const float av = acc[r];
-        if (__builtin_fabsf(av) < delta && jok && irow < c.ni) {
-          const Pos<float> pi = a.sorted[c.ibeg + irow];
-          const float dx = sub_rn(pj.x, pi.x), dy = sub_rn(pj.y, pi.y), dz = sub_rn(pj.z, pi.z);
-          const float r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-          const bool want = !(r2 > a.rc2), have = (__float_as_uint(av) >> 31) != 0;
-          if (want != have && gi[r] < gj) bits[r] ^= 1u;
-          if (a.dbg & 8) atomicAdd(a.dbg_buf + 0, 1ull);
-        }
-      }
+    for (int r = 0; r < 4; r++) {
+      const int32_t irow = i0 + 4 * kq + r;
+      const Pos<float> pi = mf_load_pos_blocking(a.sorted + c.ibeg + min(irow, c.ni - 1));
+      const float dx = sub_rn(pj.x, pi.x), dy = sub_rn(pj.y, pi.y), dz = sub_rn(pj.z, pi.z);
+      const float r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+      const bool want = !(r2 > a.rc2) && gi[r] < gj && jok && irow < c.ni;
+      bits[r] = (bits[r] & ~(1u << pos)) | ((want ? 1u : 0u) << pos);
     }
+    if (a.dbg & 8) atomicAdd(a.dbg_buf + 0, 1ull);
   };
 
   // The unit's tiles are t = res, res + 4, res + 8, ...: step s tests the 16 staged particles (res + 4 s)*16 + lam,
-  // i.e. particle s*64 + (res*16 + lam) -- word res*16 + lam, bit s of the LANE64 mask layout that k_fill_masks
-  // expands (search_group writes the same words): the four units of an i-block own 16 words each.
-  const int32_t ns = a.dbg & 1 ? 0 : (ntiles - res + 3) >> 2;  // steps of this unit (<= 20)
+  // i.e. particle s*64 + (res*16 + lam) -- word res*16 + lam, bit s of the mask layout that k_fill_masks expands
+  // (search_group writes the same words): the four units of an i-block own 16 words each.
+  const int32_t ns = a.dbg & 1 ? 0 : (ntiles - res + 3) >> 2;  // steps of this unit (<= 18)
 #pragma unroll
   for (int r = 0; r < 4; r++) bits[r] = 0;
   if (ns > 0) {
-    const int32_t s_last = ns - 1;
-    // Two accumulators in ping-pong: the MFMA of the next step is issued before the vector work of the current
-    // one.  Steps beyond the last are clamped (the result of such an MFMA is never consumed).
+    // Two steps per trip, two accumulators: the MFMA of step s + 2 is issued as soon as step s has been consumed, so
+    // it runs under the vector work of step s + 1.  Operands are fetched two steps ahead with one running pointer
+    // (consecutive steps of a wave are 64 dwords apart: ds_read2st64_b32); the fetches past the last step read the
+    // pad of the arrays, and the MFMAs fed with them are never consumed.
+    constexpr int STRIDE = 4 * MF_TILE;
+    const float* pb = bp + res * MF_TILE;
+    const int32_t* pg = gp + res * MF_TILE;
+    float b0 = pb[0], b1 = pb[STRIDE];
+    int32_t g0 = pg[0], g1 = pg[STRIDE];
+    f32x4 acc0 = mma(b0), acc1 = mma(b1);
+    for (int32_t s_ = 0; s_ < ns; s_ += 2) {
+      pb += 2 * STRIDE, pg += 2 * STRIDE;
 #ifdef MF_ABL_NO_LDS  // ablation: every step reads the same tile (the loads are hoisted out of the loop)
-    auto tix = [&](int32_t) { return res * MF_TILE; };
+      const float nb0 = b0, nb1 = b1;
+      const int32_t ng0 = g0, ng1 = g1;
 #else
-    auto tix = [&](int32_t s_) { return (res + 4 * min(s_, s_last)) * MF_TILE; };
+      const float nb0 = pb[0], nb1 = pb[STRIDE];
+      const int32_t ng0 = pg[0], ng1 = pg[STRIDE];
 #endif
-    float bv0 = bp[tix(0)], bv1 = bp[tix(1)];
-    int32_t g0 = gp[tix(0)], g1 = gp[tix(1)];
-    f32x4 acc0 = mma(bv0), acc1;
-    for (int32_t s_ = 0; s_ <= s_last; s_ += 2) {
-      acc1 = mma(bv1);
-      bv0 = bp[tix(s_ + 2)];
-      const int32_t g0n = gp[tix(s_ + 2)];
-      process(acc0, g0, res + 4 * s_);
-      acc0 = mma(bv0);
-      bv1 = bp[tix(s_ + 3)];
-      const int32_t g1n = gp[tix(s_ + 3)];
-      if (s_ + 1 <= s_last) process(acc1, g1, res + 4 * (s_ + 1));
-      g0 = g0n, g1 = g1n;
+      const bool two = s_ + 1 < ns;
+      float m = process(acc0, g0, __builtin_huge_valf());
+      acc0 = mma(nb0);
+      if (two) m = process(acc1, g1, m);
+      acc1 = mma(nb1);
+#ifndef MF_ABL_NO_UNC  // tools/mfma_bench ablation: no band check at all (timing only, results wrong)
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(m < delta) != 0, 0)) {
+        retest(res + 4 * s_, g0, two ? 1u : 0u);
+        if (two) retest(res + 4 * (s_ + 1), g1, 0u);
+      }
+#endif
+      g0 = ng0, g1 = ng1;
     }
   }
 #pragma unroll
@@ -356,7 +371,7 @@ __device__ __forceinline__ void mf_cell(const SweepArgs<float>& a) {
   mf_stamp(a, tid, 5, t_prev);  // counts
 }
 
-__global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f32(SweepArgs<float> a) { mf_cell<false>(a); }
-__global__ void __launch_bounds__(MF_WAVES* WAVE, 8) k_sweep_mfma_f16(SweepArgs<float> a) { mf_cell<true>(a); }
+__global__ void __launch_bounds__(MF_WAVES* WAVE, 6) k_sweep_mfma_f32(SweepArgs<float> a) { mf_cell<false>(a); }
+__global__ void __launch_bounds__(MF_WAVES* WAVE, 6) k_sweep_mfma_f16(SweepArgs<float> a) { mf_cell<true>(a); }
 
 }  // namespace nl
