@@ -227,11 +227,11 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
 
 // FULL = the list keeps both directions of every pair (the reference GPU class's contract); the persistent and
 // matrix-core variants exist for the half list only and are not selected for a full build (enqueue_build).
-template <typename T, bool FULL> void launch_sweep_kind(nl_handle_t h, int mode, hipStream_t s) {
+template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h, int mode, hipStream_t s) {
   const int32_t owned_layers = h->b_slab ? h->b_mzl - 2 : h->b_mzl;
   const int32_t ncells_i = h->m[0] * h->m[1] * owned_layers;
   const SweepArgs<T> a = sweep_args<T>(h);
-  if constexpr (sizeof(T) == 4 && !FULL) {
+  if constexpr (sizeof(T) == 4 && !FULL && !PBC) {
     if (h->b_variant == 2) {
       // persistent kernel: 4 workgroups of 8 waves per CU (2 x 20 KiB LDS each), each walking a run of cells
       const int32_t grid = std::max(8, std::min(h->dbg_wg_per_cu * h->num_cus, (ncells_i + 1) / 2 / 8 * 8));
@@ -252,7 +252,7 @@ template <typename T, bool FULL> void launch_sweep_kind(nl_handle_t h, int mode,
   if (h->b_use_masks) {
     if (mode == MODE_COUNT) {
       if constexpr (sizeof(T) == 4) {
-        if constexpr (!FULL) {
+        if constexpr (!FULL && !PBC) {
           if (h->b_use_mfma) {
             if (h->b_variant == 5)
               hipLaunchKernelGGL(k_sweep_mfma_f16, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
@@ -261,32 +261,35 @@ template <typename T, bool FULL> void launch_sweep_kind(nl_handle_t h, int mode,
             return;
           }
         }
-        hipLaunchKernelGGL(k_sweep_count_masks_f32<FULL>, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), h->dbg_lds_pad, s, a);
+        hipLaunchKernelGGL((k_sweep_count_masks_f32<FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), h->dbg_lds_pad, s, a);
       } else
-        hipLaunchKernelGGL((k_sweep<T, MODE_COUNT_MASKS, FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+        hipLaunchKernelGGL((k_sweep<T, MODE_COUNT_MASKS, FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
     } else {
       const int32_t nbp = (h->n + 255) / 256;
       if (h->n > 0)
         hipLaunchKernelGGL(k_row_base, dim3(nbp), dim3(256), 0, s, h->key_pointer, h->sorted_row, h->n_rows, h->n,
                            h->base_sorted);
-      hipLaunchKernelGGL((k_fill_masks<T, FULL>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
+      hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
     }
     return;
   }
   if (mode == MODE_COUNT) {
     if constexpr (sizeof(T) == 4)
-      hipLaunchKernelGGL(k_sweep_count_f32<FULL>, dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+      hipLaunchKernelGGL((k_sweep_count_f32<FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
     else
-      hipLaunchKernelGGL((k_sweep<T, MODE_COUNT, FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+      hipLaunchKernelGGL((k_sweep<T, MODE_COUNT, FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
   } else
-    hipLaunchKernelGGL((k_sweep<T, MODE_FILL, FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+    hipLaunchKernelGGL((k_sweep<T, MODE_FILL, FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
 }
 
 template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) {
-  if (h->b_full)
-    launch_sweep_kind<T, true>(h, mode, s);
-  else
-    launch_sweep_kind<T, false>(h, mode, s);
+  if (h->b_full) {
+    if (h->pbc) launch_sweep_kind<T, true, true>(h, mode, s);
+    else launch_sweep_kind<T, true, false>(h, mode, s);
+  } else {
+    if (h->pbc) launch_sweep_kind<T, false, true>(h, mode, s);
+    else launch_sweep_kind<T, false, false>(h, mode, s);
+  }
 }
 
 // Enqueues one whole build. ev != nullptr: records an event before every stage and one after the last.
@@ -751,7 +754,7 @@ int nl_debug_occupancy(int32_t out[8]) {
   out[2] = v;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_p<float, MODE_FILL>, PW * WAVE, 0);
   out[3] = v;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_count_f32<false>, SWEEP_WAVES * WAVE, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_count_f32<false, false>, SWEEP_WAVES * WAVE, 0);
   out[4] = v;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep<float, MODE_FILL>, SWEEP_WAVES * WAVE, 0);
   out[5] = v;

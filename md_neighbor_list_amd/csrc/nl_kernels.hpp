@@ -697,7 +697,7 @@ template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs
 }
 
 // The pair search of one cell: stage the stencil stream into `tile` (in batches of CAP), search it group by group.
-template <typename T, int MODE, int CAP = SweepCfg<T>::CAP, int NW = SWEEP_WAVES, bool FULL = false>
+template <typename T, int MODE, int CAP = SweepCfg<T>::CAP, int NW = SWEEP_WAVES, bool FULL = false, bool PBC = false>
 __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx& c, Pos<T>* tile, int tid, int lane,
                                             int wave) {
   constexpr int G = SWEEP_G;
@@ -722,19 +722,24 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       if (len == 0) continue;
       const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
       const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg) - win0;
-      // minimum-image mode: a segment reached through a periodic face is staged at its image (uniform per segment)
-      const int32_t wr = a.pbc ? __builtin_amdgcn_readlane(c.wrap, sg) : 0x15;
-      const bool shifted = wr != 0x15;
-      const T sx = (T)((wr & 3) - 1) * a.L[0], sy = (T)(((wr >> 2) & 3) - 1) * a.L[1], sz = (T)(((wr >> 4) & 3) - 1) * a.L[2];
+      // minimum-image kernels (PBC): a segment reached through a periodic face is staged at its image.  Uniform per
+      // segment; a template parameter because even a never-taken run-time branch here cost the open-box path 3-6 %.
+      const int32_t wr = PBC ? __builtin_amdgcn_readlane(c.wrap, sg) : 0x15;  // (compile-time: the open-box kernels
+                                                                              // carry none of this)
+      if (PBC && wr != 0x15) {
+        const T sx = (T)((wr & 3) - 1) * a.L[0], sy = (T)(((wr >> 2) & 3) - 1) * a.L[1], sz = (T)(((wr >> 4) & 3) - 1) * a.L[2];
+        for (int32_t k = lane; k < len; k += WAVE) {
+          Pos<T> v0 = a.sorted[src + k];
+          v0.x = add_rn(v0.x, sx), v0.y = add_rn(v0.y, sy), v0.z = add_rn(v0.z, sz);
+          if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) tile[off + k] = v0;
+        }
+        continue;
+      }
       for (int32_t k = lane; k < len; k += 2 * WAVE) {
         const int32_t k1 = k + WAVE;
         const bool p1 = k1 < len;
-        Pos<T> v0 = a.sorted[src + k];
-        Pos<T> v1 = a.sorted[src + (p1 ? k1 : k)];
-        if (shifted) {
-          v0.x = add_rn(v0.x, sx), v0.y = add_rn(v0.y, sy), v0.z = add_rn(v0.z, sz);
-          v1.x = add_rn(v1.x, sx), v1.y = add_rn(v1.y, sy), v1.z = add_rn(v1.z, sz);
-        }
+        const Pos<T> v0 = a.sorted[src + k];
+        const Pos<T> v1 = a.sorted[src + (p1 ? k1 : k)];
         if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) tile[off + k] = v0;
         if (p1 && (nbatch == 1 || (uint32_t)(off + k1) < (uint32_t)CAP)) tile[off + k1] = v1;
       }
@@ -790,7 +795,8 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
   }
 }
 
-template <typename T, int MODE, bool FULL = false> __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
+template <typename T, int MODE, bool FULL = false, bool PBC = false>
+__device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   __shared__ Pos<T> tile[SweepCfg<T>::CAP];
   if (MODE == MODE_FILL) {
     if (a.total[0] > a.capacity) {  // uniform: every workgroup leaves, nothing is written out of bounds
@@ -801,25 +807,25 @@ template <typename T, int MODE, bool FULL = false> __device__ __forceinline__ vo
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   CellCtx c;
   if (!cell_setup(a, lane, c)) return;
-  cell_search<T, MODE, SweepCfg<T>::CAP, SWEEP_WAVES, FULL>(a, c, tile, tid, lane, wave);
+  cell_search<T, MODE, SweepCfg<T>::CAP, SWEEP_WAVES, FULL, PBC>(a, c, tile, tid, lane, wave);
 }
 
-template <typename T, int MODE, bool FULL = false>
+template <typename T, int MODE, bool FULL = false, bool PBC = false>
 __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_sweep(SweepArgs<T> a) {
-  sweep_cell<T, MODE, FULL>(a);
+  sweep_cell<T, MODE, FULL, PBC>(a);
 }
 // The fp32 COUNT passes are held to 80 SGPRs: the SGPR file admits 8 waves per SIMD only up to 80 per wave (6 at
 // the 102 the compiler takes by itself).  FILL needs the extra SGPRs (cursors + masks): capped, it spills into its
 // inner loop and loses more than the occupancy gains.
-template <bool FULL = false>
+template <bool FULL = false, bool PBC = false>
 __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_sweep_count_f32(SweepArgs<float> a) {
-  sweep_cell<float, MODE_COUNT, FULL>(a);
+  sweep_cell<float, MODE_COUNT, FULL, PBC>(a);
 }
-template <bool FULL = false>
+template <bool FULL = false, bool PBC = false>
 __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_sweep_count_masks_f32(SweepArgs<float> a) {
-  sweep_cell<float, MODE_COUNT_MASKS, FULL>(a);
+  sweep_cell<float, MODE_COUNT_MASKS, FULL, PBC>(a);
 }
 
 // ------------------------------------------------------------------------------------------ list from masks
@@ -842,7 +848,7 @@ __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan ov
 
 constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
 
-template <typename T, bool FULL = false>
+template <typename T, bool FULL = false, bool PBC = false>
 __global__ void __launch_bounds__(EXPAND_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
 k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
@@ -860,7 +866,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
     // No masks for this cell (its stencil needed several LDS batches in COUNT_MASKS): search it again, as
     // k_sweep<FILL> does, in small batches through the id buffer.  Rare (very dense cells only).
     constexpr int CAPS = (int)(CAP * sizeof(int32_t) / (sizeof(Pos<T>))) / WAVE * WAVE;
-    cell_search<T, MODE_FILL, CAPS, EW, FULL>(a, c, reinterpret_cast<Pos<T>*>(gids), tid, lane, wave);
+    cell_search<T, MODE_FILL, CAPS, EW, FULL, PBC>(a, c, reinterpret_cast<Pos<T>*>(gids), tid, lane, wave);
     return;
   }
 
