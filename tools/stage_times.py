@@ -9,8 +9,14 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from md_neighbor_list_amd import NeighListGPU, inputs, _lib  # noqa: E402
 
-if os.environ.get("NL_LIB"):  # development only: A/B another build of the library in the same session
+if os.environ.get("NL_LIB"):  # development only: A/B another (possibly older) build of the library in the same session
+    import ctypes
+
     _lib.LIB_PATH = os.path.abspath(os.environ["NL_LIB"])
+    _old = ctypes.CDLL(_lib.LIB_PATH)
+    for _name in list(_lib.PROTOTYPES):
+        if not hasattr(_old, _name):
+            del _lib.PROTOTYPES[_name]
 
 CFGS = {
     "cfg2": (1 << 20, 1.0, 3.3, np.float32),
