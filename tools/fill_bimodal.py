@@ -23,3 +23,13 @@ for trial in range(8):
         keep.append(nl)  # keep some handles alive so that later ones land at other addresses
     pad = torch.empty((trial + 1) * 1234567, dtype=torch.uint8, device="cuda")
     keep.append(pad)
+
+print("-- one handle, the list re-allocated at other addresses (nl_set_capacity)")
+nl = NeighListGPU(3.3, *box, dtype=torch.float32)
+nl.Initialize(len(q))
+for trial in range(10):
+    nl.set_capacity(100_000_000 + trial * 3_000_017)
+    st = nl.profile_stages(qd, reps=10)
+    a = nl.sorted_list().data_ptr()
+    print(f"capacity trial {trial}: fill {st['fill'] * 1e3:.1f} us count {st['count'] * 1e3:.1f} us  list@{a:#x} (list mod 1GiB = {a % (1 << 30):#x})", flush=True)
+    keep.append(torch.empty((trial + 1) * 7654321, dtype=torch.uint8, device="cuda"))

@@ -26,6 +26,10 @@ CFGS = {
     "fcc": None,
 }
 
+_pre = None
+if os.environ.get("PREALLOC_MB"):  # experiment: what the allocations that come before the handle do to the timings
+    _pre = torch.empty(int(os.environ["PREALLOC_MB"]) << 20, dtype=torch.uint8, device="cuda")
+
 for name in sys.argv[1:] or ["cfg2", "cfg3"]:
     if name == "fcc":
         q, box = inputs.fcc_box(1.0, 50.0, np.float64)
