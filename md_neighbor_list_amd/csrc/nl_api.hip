@@ -52,6 +52,7 @@ struct nl_handle_s {
   int32_t* rank = nullptr;
   void* sorted = nullptr;
   int32_t* sorted_row = nullptr;
+  int32_t* sorted_gid = nullptr;   // ids in cell order, compact
   int32_t* count = nullptr;
   int32_t* key_pointer = nullptr;
   int32_t* progress = nullptr;
@@ -201,6 +202,7 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   SweepArgs<T> a;
   a.sorted = static_cast<const Pos<T>*>(h->sorted);
   a.sorted_row = h->sorted_row;
+  a.sorted_gid = h->sorted_gid;
   a.cell_start = h->cell_start;
   a.mx = h->m[0], a.my = h->m[1], a.mzl = h->b_mzl, a.slab = h->b_slab;
   a.div_mx = fastdiv_make((uint32_t)h->m[0]), a.div_my = fastdiv_make((uint32_t)h->m[1]);
@@ -328,7 +330,7 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
                          nrows, h->row_start, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row);
     hipLaunchKernelGGL((k_bin_cells<T>), dim3(nrows), dim3(256), 0, s, g, nrows, h->row_start,
                        static_cast<const Pos<T>*>(h->tmp_pos), h->tmp_row, h->cell_start, static_cast<Pos<T>*>(h->sorted),
-                       h->sorted_row);
+                       h->sorted_row, h->sorted_gid);
   } else {
     HIPCHK(h, hipMemsetAsync(h->cell_count, 0, sizeof(int32_t) * (size_t)(h->ncell + 32), s));
     if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
@@ -338,7 +340,7 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
     if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_REORDER], s));
     if (n > 0)
       hipLaunchKernelGGL((k_reorder<T>), dim3(nbp), dim3(256), 0, s, q, stride, gid, n, g, h->cell_start, h->rank,
-                         static_cast<Pos<T>*>(h->sorted), h->sorted_row);
+                         static_cast<Pos<T>*>(h->sorted), h->sorted_row, h->sorted_gid);
   }
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_COUNT], s));
   // (rows of particles rejected by the hash keep a stale count: such a build fails with its status anyway)
@@ -525,7 +527,7 @@ int nl_destroy(nl_handle_t h) {
   if (!h) return NL_ERR_ARG;
   (void)hipSetDevice(h->device);
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
-  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->count, h->key_pointer, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->dbg_buf, h->cell_count,
+  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->dbg_buf, h->cell_count,
                   h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -551,6 +553,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   if ((rc = dev_alloc(h, &h->rank, 4 * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->sorted, pos_bytes * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->sorted_row, 4 * (n + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->sorted_gid, 4 * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->count, 4 * (n + 32)))) return rc;
   if ((rc = dev_alloc(h, &h->key_pointer, 4 * (n + 32)))) return rc;
   if ((rc = dev_alloc(h, &h->progress, 4 * (n + 16)))) return rc;

@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) k_reorder(const T* __restrict__ q, int32_
                                                   const int32_t* __restrict__ gid, int32_t n, Grid<T> g,
                                                   const int32_t* __restrict__ cell_start,
                                                   const int32_t* __restrict__ rank, Pos<T>* __restrict__ sorted,
-                                                  int32_t* __restrict__ sorted_row) {
+                                                  int32_t* __restrict__ sorted_row, int32_t* __restrict__ sorted_gid) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t r = rank[i];
@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(256) k_reorder(const T* __restrict__ q, int32_
   if constexpr (sizeof(T) == 8) p.row = i;
   sorted[dst] = p;
   sorted_row[dst] = i;
+  sorted_gid[dst] = p.gid;
 }
 
 // ---------------------------------------------------------------------------------------------- scans
@@ -430,7 +431,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, const int32_t* __restrict__ row_start,
                                                    const Pos<T>* __restrict__ tmp, const int32_t* __restrict__ tmp_row,
                                                    int32_t* __restrict__ cell_start, Pos<T>* __restrict__ sorted,
-                                                   int32_t* __restrict__ sorted_row) {
+                                                   int32_t* __restrict__ sorted_row, int32_t* __restrict__ sorted_gid) {
   __shared__ int32_t cnt[BIN_MAX_MX];
   __shared__ int32_t wsum[4];
   __shared__ int32_t carry_s;
@@ -483,6 +484,7 @@ __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, con
     }
     sorted[dst] = p;
     sorted_row[dst] = tmp_row[k];
+    sorted_gid[dst] = p.gid;  // the ids alone, 4 bytes apart: what the expansion kernel stages
   }
 }
 
@@ -514,6 +516,7 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
 template <typename T> struct SweepArgs {
   const Pos<T>* __restrict__ sorted;
   const int32_t* __restrict__ sorted_row;
+  const int32_t* __restrict__ sorted_gid;  // sorted[k].gid, compact (k_fill_masks reads ids only: 4 x fewer cache lines)
   const int32_t* __restrict__ cell_start;
   int32_t mx, my, mzl, slab;
   FastDiv div_mx, div_my;         // i-cell index -> (cx, cy, cz) without integer division
@@ -846,6 +849,7 @@ __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan ov
   return v;
 }
 
+constexpr int EXPAND_RMAX = 192;  // longest row k_fill_masks assembles in LDS (longer ones are written entry by entry)
 constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
 
 template <typename T, bool FULL = false, bool PBC = false>
@@ -855,6 +859,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int EW = EXPAND_WAVES;
   // 5 KiB: ids only, so many workgroups per CU keep enough loads in flight
   __shared__ __attribute__((aligned(32))) int32_t gids[CAP];
+  __shared__ int32_t cmp[EW][4][EXPAND_RMAX];  // per wave: four rows being put together
   if (a.total[0] > a.capacity) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
     return;
@@ -889,19 +894,31 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   load_rows(r_beg);  // issued before the id staging: independent of the segment table
   if (a.dbg & 32) return;  // diagnostics: setup + loads only
 
-  // stage the ids of the stencil stream (the 4-byte id field of the 16/32-byte sorted particles)
-  for (int32_t sg = wave; sg < NSEG; sg += EW) {
-    const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
-    if (len == 0) continue;
-    const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
-    const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg);
-    for (int32_t k = lane; k < len; k += 2 * WAVE) {
-      const int32_t k1 = k + WAVE;
-      const bool p1 = k1 < len;
-      const int32_t v0 = a.sorted[src + k].gid;
-      const int32_t v1 = a.sorted[src + (p1 ? k1 : k)].gid;
-      gids[off + k] = v0;
-      if (p1) gids[off + k1] = v1;
+  // stage the ids of the stencil stream, from the compact copy of the id field
+  // All loads of the wave's segments go out before the first LDS write: loading and writing segment by segment
+  // costs one memory round trip per segment (9 per wave).
+  {
+    constexpr int SPW = (NSEG + EW - 1) / EW;  // segments per wave
+    int32_t v0[SPW], v1[SPW];
+#pragma unroll
+    for (int s = 0; s < SPW; s++) {
+      const int sg = min(wave + s * EW, NSEG - 1);  // wave-uniform
+      const int32_t len = wave + s * EW < NSEG ? __builtin_amdgcn_readlane(c.seg_len, sg) : 0;
+      const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
+      // clamped, unconditional loads (an empty segment reads slot 0 of the array)
+      const int32_t k0 = len > 0 ? src + min(lane, len - 1) : 0, k1 = len > 0 ? src + min(lane + WAVE, len - 1) : 0;
+      v0[s] = a.sorted_gid[k0];
+      v1[s] = a.sorted_gid[k1];
+    }
+#pragma unroll
+    for (int s = 0; s < SPW; s++) {
+      const int sg = min(wave + s * EW, NSEG - 1);
+      const int32_t len = wave + s * EW < NSEG ? __builtin_amdgcn_readlane(c.seg_len, sg) : 0;
+      const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
+      const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg);
+      if (lane < len) gids[off + lane] = v0[s];
+      if (lane + WAVE < len) gids[off + lane + WAVE] = v1[s];
+      for (int32_t k = lane + 2 * WAVE; k < len; k += WAVE) gids[off + k] = a.sorted_gid[src + k];  // > 128: dense cells
     }
   }
   __syncthreads();  // ids staged
@@ -915,21 +932,65 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
     for (int u0 = 0; u0 < RB; u0 += 4) {
       if (r0 + u0 >= r_end) continue;  // wave-uniform
       uint32_t word[4], ptr[4];
+      int32_t nrow[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         word[q] = r0 + u0 + q < r_end ? w[u0 + q] : 0u;
         if (a.dbg & 16) word[q] = 0;  // diagnostics: no expansion
         const int32_t cnt = __popc(word[q]);
-        ptr[q] = (uint32_t)(base[u0 + q] + scan64_dpp(cnt) - cnt);
+        const int32_t incl = scan64_dpp(cnt);
+        nrow[q] = __builtin_amdgcn_readlane(incl, 63);
+        ptr[q] = (uint32_t)(incl - cnt);  // place inside the row
       }
-      while (word[0] | word[1] | word[2] | word[3]) {
+      const int32_t nmax = max(max(nrow[0], nrow[1]), max(nrow[2], nrow[3]));
+      if (nmax <= EXPAND_RMAX) {
+        // The set bits of a lane are consecutive entries of the row, but one trip through the bit loop writes one
+        // entry per lane: ~13 lanes spread over the whole 290-byte row, 5-6 trips per row (8 for a full list).  So
+        // the row is put together in LDS first (same loop, ds_write instead of a global store) and leaves as
+        // 64-entry runs: 2-3 store instructions per row, each to consecutive addresses.
+        int32_t* const cw = &cmp[wave][0][0];
+#pragma unroll
+        for (int q = 0; q < 4; q++) ptr[q] += q * EXPAND_RMAX;
+        while (word[0] | word[1] | word[2] | word[3]) {
+          int32_t val[4];
+          bool on[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            on[q] = word[q] != 0;
+            const int32_t t = on[q] ? __ffs(word[q]) - 1 : 0;
+            val[q] = g[t * WAVE];  // unconditional read of a valid slot: the four reads go out back to back
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            if (on[q]) {
+              cw[ptr[q]] = val[q];
+              ptr[q]++;
+              word[q] &= word[q] - 1;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // the buffer is private to the wave: LDS executes its accesses in order
+        for (int32_t e = lane; e - lane < nmax; e += WAVE) {
+          int32_t val[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) val[q] = cw[q * EXPAND_RMAX + min(e, EXPAND_RMAX - 1)];
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (e < nrow[q]) a.list[(size_t)base[u0 + q] + e] = val[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) ptr[q] += (uint32_t)base[u0 + q];
+      while (word[0] | word[1] | word[2] | word[3]) {  // a very long row: straight to memory
         int32_t val[4];
         bool on[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           on[q] = word[q] != 0;
           const int32_t t = on[q] ? __ffs(word[q]) - 1 : 0;
-          val[q] = g[t * WAVE];  // unconditional read of a valid slot: the four reads go out back to back
+          val[q] = g[t * WAVE];
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {

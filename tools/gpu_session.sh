@@ -31,6 +31,8 @@ for s in $STEPS; do
     smoke) run 300 "$OUT/smoke.log" python -c "import __graft_entry__ as g; g.smoke()"; tail -3 "$OUT/smoke.log" ;;
     mfbench) run 120 "$OUT/mfma_bench.log" ./tools/mfma_bench; cat "$OUT/mfma_bench.log" ;;
     mfcheck) run 60 "$OUT/mfma_check.log" ./tools/mfma_check; cat "$OUT/mfma_check.log" ;;
+    fillab) run 300 "$OUT/fill_ab.log" python tools/fill_ab.py; cat "$OUT/fill_ab.log" ;;
+    bwprobe) run 300 "$OUT/bw_probe.log" python tools/bw_probe.py; cat "$OUT/bw_probe.log" ;;
     dbgpar) run 300 "$OUT/debug_parity.log" python tools/debug_parity.py; cat "$OUT/debug_parity.log" ;;
     stages) run 300 "$OUT/stages.log" python tools/stage_times.py; cat "$OUT/stages.log" ;;
     sbench) run 120 "$OUT/search_bench.log" ./tools/search_bench; cat "$OUT/search_bench.log" ;;
