@@ -858,8 +858,10 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
   constexpr int EW = EXPAND_WAVES;
   // 5 KiB: ids only, so many workgroups per CU keep enough loads in flight
-  __shared__ __attribute__((aligned(32))) int32_t gids[CAP];
-  __shared__ int32_t cmp[EW][4][EXPAND_RMAX];  // per wave: four rows being put together
+  // One LDS array (a second __shared__ object next to an LDS-DMA target makes hipcc drain the DMA before every
+  // ds_read): the ids of the stencil stream (4.5 KiB) + per wave four rows being put together.
+  __shared__ __attribute__((aligned(32))) int32_t lds[CAP + EW * 4 * EXPAND_RMAX];
+  int32_t* const gids = lds;
   if (a.total[0] > a.capacity) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
     return;
@@ -895,30 +897,19 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   if (a.dbg & 32) return;  // diagnostics: setup + loads only
 
   // stage the ids of the stencil stream, from the compact copy of the id field
-  // All loads of the wave's segments go out before the first LDS write: loading and writing segment by segment
-  // costs one memory round trip per segment (9 per wave).
-  {
-    constexpr int SPW = (NSEG + EW - 1) / EW;  // segments per wave
-    int32_t v0[SPW], v1[SPW];
+  // LDS-DMA (global_load_lds_dword: lane l's dword lands at the uniform LDS address + 4 l): no VGPRs and no LDS
+  // write instructions, and every segment's loads are in flight together.  (Loading and writing segment by segment
+  // through registers cost one memory round trip per segment, 9 per wave.)
 #pragma unroll
-    for (int s = 0; s < SPW; s++) {
-      const int sg = min(wave + s * EW, NSEG - 1);  // wave-uniform
-      const int32_t len = wave + s * EW < NSEG ? __builtin_amdgcn_readlane(c.seg_len, sg) : 0;
-      const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
-      // clamped, unconditional loads (an empty segment reads slot 0 of the array)
-      const int32_t k0 = len > 0 ? src + min(lane, len - 1) : 0, k1 = len > 0 ? src + min(lane + WAVE, len - 1) : 0;
-      v0[s] = a.sorted_gid[k0];
-      v1[s] = a.sorted_gid[k1];
-    }
-#pragma unroll
-    for (int s = 0; s < SPW; s++) {
-      const int sg = min(wave + s * EW, NSEG - 1);
-      const int32_t len = wave + s * EW < NSEG ? __builtin_amdgcn_readlane(c.seg_len, sg) : 0;
-      const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
-      const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg);
-      if (lane < len) gids[off + lane] = v0[s];
-      if (lane + WAVE < len) gids[off + lane + WAVE] = v1[s];
-      for (int32_t k = lane + 2 * WAVE; k < len; k += WAVE) gids[off + k] = a.sorted_gid[src + k];  // > 128: dense cells
+  for (int s = 0; s < (NSEG + EW - 1) / EW; s++) {
+    const int sg = min(wave + s * EW, NSEG - 1);  // wave-uniform
+    const int32_t len = wave + s * EW < NSEG ? __builtin_amdgcn_readlane(c.seg_len, sg) : 0;
+    const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
+    const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg);
+    for (int32_t kb = 0; kb < len; kb += WAVE) {
+      if (kb + lane < len)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.sorted_gid + src + kb + lane),
+                                         (__attribute__((address_space(3))) void*)(gids + off + kb), 4, 0, 0);
     }
   }
   __syncthreads();  // ids staged
@@ -948,7 +939,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
         // entry per lane: ~13 lanes spread over the whole 290-byte row, 5-6 trips per row (8 for a full list).  So
         // the row is put together in LDS first (same loop, ds_write instead of a global store) and leaves as
         // 64-entry runs: 2-3 store instructions per row, each to consecutive addresses.
-        int32_t* const cw = &cmp[wave][0][0];
+        int32_t* const cw = lds + CAP + wave * 4 * EXPAND_RMAX;
 #pragma unroll
         for (int q = 0; q < 4; q++) ptr[q] += q * EXPAND_RMAX;
         while (word[0] | word[1] | word[2] | word[3]) {
