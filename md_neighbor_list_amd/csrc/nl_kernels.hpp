@@ -849,26 +849,31 @@ __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan ov
   return v;
 }
 
-constexpr int EXPAND_RMAX = 192;  // longest row k_fill_masks assembles in LDS (longer ones are written entry by entry)
+// longest row k_fill_masks assembles in LDS (longer ones are written entry by entry); half list: 5 + 5 KiB of LDS =
+// 16 workgroups per CU
+template <bool FULL> constexpr int EXPAND_RMAX_OF = FULL ? 192 : 160;
 constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
 
 template <typename T, bool FULL = false, bool PBC = false>
-__global__ void __launch_bounds__(EXPAND_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(EXPAND_WAVES* WAVE, (sizeof(T) == 4 ? (FULL ? 7 : 8) : 4)) __attribute__((amdgpu_num_sgpr(80)))
 k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
   constexpr int EW = EXPAND_WAVES;
+  constexpr int EXPAND_RMAX = EXPAND_RMAX_OF<FULL>;
   // 5 KiB: ids only, so many workgroups per CU keep enough loads in flight
   // One LDS array (a second __shared__ object next to an LDS-DMA target makes hipcc drain the DMA before every
   // ds_read): the ids of the stencil stream (4.5 KiB) + per wave four rows being put together.
   __shared__ __attribute__((aligned(32))) int32_t lds[CAP + EW * 4 * EXPAND_RMAX];
   int32_t* const gids = lds;
-  if (a.total[0] > a.capacity) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t total = a.total[0];  // read together with the cell table: one round trip, not two
+  CellCtx c;
+  const bool ok = cell_setup(a, lane, c);
+  if (total > a.capacity) {  // the list is too small: the host grows it and runs this kernel again
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
     return;
   }
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  CellCtx c;
-  if (!cell_setup(a, lane, c)) return;
+  if (!ok) return;
   if (c.total_j > CAP) {
     // No masks for this cell (its stencil needed several LDS batches in COUNT_MASKS): search it again, as
     // k_sweep<FILL> does, in small batches through the id buffer.  Rare (very dense cells only).
