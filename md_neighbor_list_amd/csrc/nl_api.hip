@@ -571,7 +571,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
     if ((rc = dev_alloc(h, &h->tmp_pos, pos_bytes * (n + 16)))) return rc;
     if ((rc = dev_alloc(h, &h->tmp_row, 4 * (n + 16)))) return rc;
   }
-  if (h->sweep_variant >= 3 && (rc = dev_alloc(h, &h->masks, 4 * (size_t)WAVE * (n + 16)))) return rc;
+  if (h->sweep_variant >= 3 && (rc = dev_alloc(h, &h->masks, (size_t)MASK_ROW_BYTES * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->dbg_buf, 8 * (64 + 4 * 4096)))) return rc;
   HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
   if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64 + (size_t)h->m[1] * h->m[2])))) return rc;

@@ -535,12 +535,27 @@ template <typename T> struct SweepArgs {
   T delta;                        // k_sweep_mfma_f32: |r2 - rc2| below this is re-tested exactly
   T delta16, mf_scale, mf_scale2; // k_sweep_mfma_f16: the band in scaled units, the power-of-two scale and its square
   int32_t z_origin;               // global z layer of local layer 0
-  uint32_t* __restrict__ masks;  // [n][64]: bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
+  uint32_t* __restrict__ masks;  // [n] rows of 64 x 24 bits (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
   int32_t dbg;  // diagnostics only (NL_DEBUG_FLAGS): 1 = skip the search, 2 = skip the staging copy; 0 in production
 };
 
 template <typename T> struct SweepCfg;
+// Hit masks in memory: one row of 64 x 24 bits per sorted slot (lane l's word at byte 3 l of the 192-byte row; a
+// staged stream has at most CAP / 64 = 20 tiles).  The expansion kernel is bound by what it reads, so the unused
+// byte of a 32-bit word per lane is not stored.  Unaligned accesses: the compiler picks what the target allows.
+constexpr int MASK_ROW_BYTES = 192;
+struct __attribute__((packed)) MaskU16 { uint16_t v; };
+struct __attribute__((packed)) MaskU32 { uint32_t v; };
+__device__ __forceinline__ void mask_store(uint32_t* masks, size_t slot, int lane, uint32_t bits) {
+  char* const p = reinterpret_cast<char*>(masks) + slot * MASK_ROW_BYTES + 3 * lane;
+  reinterpret_cast<MaskU16*>(p)->v = (uint16_t)bits;
+  *reinterpret_cast<uint8_t*>(p + 2) = (uint8_t)(bits >> 16);
+}
+__device__ __forceinline__ uint32_t mask_load(const uint32_t* masks, size_t slot, int lane) {  // high byte: the next lane's
+  const char* const p = reinterpret_cast<const char*>(masks) + slot * MASK_ROW_BYTES + 3 * lane;
+  return reinterpret_cast<const MaskU32*>(p)->v;
+}
 template <> struct SweepCfg<float> { static constexpr int CAP = 1280; };   // 20 KB of LDS: 8 workgroups = 32 waves per CU
 template <> struct SweepCfg<double> { static constexpr int CAP = 1280; };  // 40 KB of LDS (registers, not LDS, limit fp64 occupancy)
 
@@ -559,7 +574,7 @@ template <typename T, int MODE, int GC, bool FULL = false>
 __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos<T>* tile, int32_t nj,
                                                 int32_t ntiles, int lane, const Pos<T>& pi_l, int32_t base_l,
                                                 int32_t slot0 = 0, bool store_masks = false) {
-  static_assert(SweepCfg<T>::CAP / WAVE <= 32, "one bit per j-tile in a 32-bit word");
+  static_assert(SweepCfg<T>::CAP / WAVE <= 24, "one bit per j-tile in the 24-bit word a lane keeps (mask_store)");
   T xi[GC], yi[GC], zi[GC];
   int32_t gi[GC];
   uint32_t cur[GC];  // COUNT: hits so far; FILL: list offset of the row + hits so far
@@ -629,7 +644,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   if (MODE == MODE_COUNT_MASKS) {
     if (store_masks) {
 #pragma unroll
-      for (int k = 0; k < GC; k++) a.masks[(size_t)(slot0 + k) * WAVE + lane] = bits[k];
+      for (int k = 0; k < GC; k++) mask_store(a.masks, (size_t)(slot0 + k), lane, bits[k]);
     }
   }
   uint32_t mine = 0;
@@ -894,7 +909,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const int32_t slot = c.ibeg + min(r0 + u, c.ni - 1);
-      w[u] = a.masks[(size_t)slot * WAVE + lane];
+      w[u] = mask_load(a.masks, (size_t)slot, lane);
       base[u] = base_sorted[slot];  // (k_row_base: one gather kernel is cheaper than two dependent loads here)
     }
   };
@@ -931,7 +946,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
       int32_t nrow[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        word[q] = r0 + u0 + q < r_end ? w[u0 + q] : 0u;
+        word[q] = r0 + u0 + q < r_end ? (w[u0 + q] & 0xFFFFFFu) : 0u;
         if (a.dbg & 16) word[q] = 0;  // diagnostics: no expansion
         const int32_t cnt = __popc(word[q]);
         const int32_t incl = scan64_dpp(cnt);

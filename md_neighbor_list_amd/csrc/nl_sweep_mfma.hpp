@@ -236,7 +236,7 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
     // step s sits at bit ns - 1 - s (v_alignbit shifts left): reverse into bit s
     const uint32_t w = ns > 0 ? __brev(bits[r]) >> (32 - ns) : 0u;
 #ifndef MF_ABL_NO_STORE
-    if (irow < c.ni) a.masks[(size_t)(c.ibeg + irow) * WAVE + res * 16 + lam] = w;
+    if (irow < c.ni) mask_store(a.masks, (size_t)(c.ibeg + irow), res * 16 + lam, w);
 #endif
     int32_t v = __popc(w);
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1 within the 16 lanes of a row group
