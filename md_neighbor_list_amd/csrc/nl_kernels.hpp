@@ -567,7 +567,7 @@ constexpr int NSEG = 18;
 // pi_l / base_l: lane k < GC holds i-particle k and the list offset of its row.  Returns, in lane k, the number
 // of accepted partners of i-particle k.  All per-i state is wave-uniform (SGPRs): position, id, running count.
 // COUNT_MASKS additionally keeps every hit: one VGPR per i-particle in which lane l sets bit t when staged
-// particle t*64 + l is accepted (2 VALU per test, no scalar work); the 64 words of an i-particle go to
+// particle t*64 + l is accepted (1 VALU per test, no scalar work); the 64 words of an i-particle go to
 // a.masks[(slot0 + k) * 64 + l] at the end (store_masks: only for cells whose stencil fits one LDS batch, which
 // also bounds t by CAP/64 <= 32).
 template <typename T, int MODE, int GC, bool FULL = false>
@@ -623,7 +623,12 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
           *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + boff) = pj.gid;
         }
       }
-      if (MODE == MODE_COUNT_MASKS) bits[k] = hit[k] ? (bits[k] | (1u << tix)) : bits[k];
+      if (MODE == MODE_COUNT_MASKS) {
+        // bits = 2 bits + hit in ONE vector instruction: add-with-carry of the word to itself, the carry-in being the
+        // hit mask (an SGPR pair).  Tile t therefore ends at bit ntiles - 1 - t; reversed once before the store.
+        uint64_t carry_out;
+        asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(bits[k]), "=s"(carry_out) : "s"(mask[k]));
+      }
       cur[k] += (uint32_t)__popcll(mask[k]);
     }
   };
@@ -644,7 +649,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   if (MODE == MODE_COUNT_MASKS) {
     if (store_masks) {
 #pragma unroll
-      for (int k = 0; k < GC; k++) mask_store(a.masks, (size_t)(slot0 + k), lane, bits[k]);
+      for (int k = 0; k < GC; k++) mask_store(a.masks, (size_t)(slot0 + k), lane, __brev(bits[k]) >> (32 - ntiles));
     }
   }
   uint32_t mine = 0;
