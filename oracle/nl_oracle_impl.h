@@ -276,9 +276,9 @@ int SUF(nl_oracle_bruteforce)(const REAL* q, int32_t stride, int64_t N, double r
  *     the pair is kept unless (double)r2 > rc2.
  * Needs >= 3 cells per axis.  Output: canonical CSR (ascending partners), as the brute force.
  */
-int SUF(nl_oracle_build_pbc)(const REAL* q, int32_t stride, int64_t N, double rc, double Lx, double Ly, double Lz,
-                             int32_t* number_of_partners, int64_t* key_pointer, int32_t** sorted_list,
-                             int64_t* npairs) {
+static int SUF(build_pbc_impl)(const REAL* q, int32_t stride, int64_t N, double rc, double Lx, double Ly, double Lz,
+                               int32_t* number_of_partners, int64_t* key_pointer, int32_t** sorted_list,
+                               int64_t* npairs, int full) {
   SUF(grid) g;
   if (N < 0 || N > 2147483647LL || stride < 3) return NLO_ERR_ARG;
   int rc_ = SUF(grid_init)(&g, rc, Lx, Ly, Lz);
@@ -290,7 +290,7 @@ int SUF(nl_oracle_build_pbc)(const REAL* q, int32_t stride, int64_t N, double rc
   int32_t* cidx = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(N > 0 ? N : 1));
   int64_t* cell_beg = (int64_t*)calloc((size_t)(M + 2), sizeof(int64_t));
   int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
-  int64_t cap = N * 64 + 1024, P = 0;
+  int64_t cap = N * (full ? 160 : 64) + 1024, P = 0;
   int32_t* out = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
   int ret = NLO_OK;
   if (!e || !cidx || !cell_beg || !ids || !out) {
@@ -340,7 +340,7 @@ int SUF(nl_oracle_build_pbc)(const REAL* q, int32_t stride, int64_t N, double rc
           const int64_t c = SUF(hash_idx)(&g, nc);
           for (int64_t b = cell_beg[c]; b < cell_beg[c + 1]; b++) {
             const int32_t j = ids[b];
-            if (j <= i) continue;
+            if (full ? j == i : j <= i) continue;
             const REAL xs = e[3 * (int64_t)j] + s[0], ys = e[3 * (int64_t)j + 1] + s[1], zs = e[3 * (int64_t)j + 2] + s[2];
             const REAL dx = xs - e[3 * i], dy = ys - e[3 * i + 1], dz = zs - e[3 * i + 2];
             const REAL r2 = dx * dx + dy * dy + dz * dz;
@@ -377,4 +377,21 @@ done:
   free(ids);
   free(out);
   return ret;
+}
+
+int SUF(nl_oracle_build_pbc)(const REAL* q, int32_t stride, int64_t N, double rc, double Lx, double Ly, double Lz,
+                             int32_t* number_of_partners, int64_t* key_pointer, int32_t** sorted_list,
+                             int64_t* npairs) {
+  return SUF(build_pbc_impl)(q, stride, N, rc, Lx, Ly, Lz, number_of_partners, key_pointer, sorted_list, npairs, 0);
+}
+
+/* The FULL minimum-image list (both directions): row i holds every j != i accepted IN THE FRAME OF i, i.e. with the
+ * image of j taken as (q_j + s) rounded to REAL, exactly as above but for all j -- what a code with ghost particles
+ * computes.  Because (q_j + s) - q_i and (q_i - s) - q_j are rounded differently, a pair whose distance is within one
+ * rounding error of the cut-off can be present in one direction only: the full list is NOT defined as the
+ * symmetrised half list in this mode (it is in the open box, where the two differences are exact negatives). */
+int SUF(nl_oracle_build_pbc_full)(const REAL* q, int32_t stride, int64_t N, double rc, double Lx, double Ly, double Lz,
+                                  int32_t* number_of_partners, int64_t* key_pointer, int32_t** sorted_list,
+                                  int64_t* npairs) {
+  return SUF(build_pbc_impl)(q, stride, N, rc, Lx, Ly, Lz, number_of_partners, key_pointer, sorted_list, npairs, 1);
 }

@@ -489,10 +489,12 @@ def test_minimum_image_mode_against_its_oracle(dtype):
         nl.Initialize(n)
         nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
         if full:
+            # row i in the frame of particle i (ghost-particle semantics), NOT the symmetrised half list: see
+            # test_minimum_image_full_list_is_evaluated_in_the_row_frame
             kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr())
-            want_kp, want_list, want_cnt = _full_from_half(ref)
-            assert np.array_equal(kp.astype(np.int64), want_kp), case
-            assert np.array_equal(canonical_csr(kp, lst), want_list), case
+            want = _po().build_pbc_full(q, rc, box)
+            assert np.array_equal(kp.astype(np.int64), want.key_pointer), case
+            assert np.array_equal(canonical_csr(kp, lst), want.sorted_list), case
         else:
             kp, sl = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
             assert int(kp[-1]) == ref.npairs, (case, int(kp[-1]), ref.npairs)
@@ -503,3 +505,46 @@ def test_minimum_image_mode_against_its_oracle(dtype):
     nl.set_full_list(False)
     nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
     assert nl.half_number_of_pairs() < ref.npairs
+
+
+def test_minimum_image_full_list_is_evaluated_in_the_row_frame():
+    """fp32, partners across a periodic face at distance rc*(1 +- k ulp): (q_j + L) - q_i and (q_i - L) - q_j round
+    differently, so some of these pairs are accepted in one direction only.  The FULL minimum-image list is defined row
+    by row in the frame of the row's particle (oracle.build_pbc_full; what a code with ghost particles computes), the
+    half list in the frame of the smaller id (oracle.build_pbc): both bit-exact, and this case must contain pairs on
+    which the two directions disagree (else it tests nothing)."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    rng = np.random.default_rng(2718)
+    rc, L = 3.3, 40.0
+    box = (L, L, L)
+    nc = 8000
+    centres = rng.uniform(0.0, L, size=(nc, 3))
+    centres[:, 0] = rng.uniform(0.0, 1.5, size=nc)  # near the low x face: most partners lie across it
+    d = rng.normal(size=(nc, 3))
+    d[:, 0] = -np.abs(d[:, 0])
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    scale = 1.0 + rng.integers(-6, 7, size=(nc, 1)) * 2.0 ** -23
+    partners = centres + d * rc * scale
+    q = np.zeros((2 * nc, 4), dtype=np.float32)
+    q[:, :3] = np.concatenate([centres, np.mod(partners, L)]).astype(np.float32)
+    q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.float32(L), np.float32(0)))
+    q = q[rng.permutation(len(q))]
+    n = len(q)
+    half, full = _po().build_pbc(q, rc, box), _po().build_pbc_full(q, rc, box)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(full.key_pointer))
+    directed = set(zip(rows.tolist(), full.sorted_list.tolist()))
+    one_way = sum((j, i) not in directed for i, j in directed)
+    assert one_way > 0, "the case must contain pairs present in one direction only"
+    for want, is_full in ((half, False), (full, True)):
+        nl = NeighListGPU(rc, *box, dtype=torch.float32, minimum_image=True, full_list=is_full)
+        nl.Initialize(n)
+        nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+        if is_full:
+            kp, lst, _ = (t.cpu().numpy() for t in nl.full_csr())
+        else:
+            kp, lst = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
+        assert np.array_equal(kp.astype(np.int64), want.key_pointer)
+        assert np.array_equal(canonical_csr(kp, lst), want.sorted_list)

@@ -127,3 +127,49 @@ def test_minimum_image_oracle_against_float64_brute_force():
         assert not (have & ~iu).any()
         assert np.array_equal(have[~near], want[~near]), case
         assert got.npairs > 0
+
+
+def test_minimum_image_full_oracle_is_the_row_frame_list():
+    """oracle build_pbc_full: row i holds every accepted j != i in the frame of i.  Its upper part (j > i) is the half
+    list exactly (same frame: the smaller id's); in float64 on random positions both directions agree, so the whole
+    list is the symmetrised half list and matches the float64 brute force; in float32 with partners placed within a
+    few ulp of the cut-off across a periodic face the two directions differ on some pairs."""
+    rng = np.random.default_rng(6)
+    rc, box = 2.5, (9.0, 10.5, 8.0)
+    n = 900
+    q = np.zeros((n, 4), dtype=np.float64)
+    q[:, :3] = rng.uniform(-0.2, 1.2, size=(n, 3)) * np.array(box)
+    half, full = po.build_pbc(q, rc, box), po.build_pbc_full(q, rc, box)
+    rows = np.repeat(np.arange(n), np.diff(full.key_pointer))
+    up = full.sorted_list > rows
+    assert np.array_equal(full.sorted_list[up], half.sorted_list)
+    assert np.array_equal(np.bincount(rows[up], minlength=n), half.number_of_partners)
+    have = np.zeros((n, n), dtype=bool)
+    have[rows, full.sorted_list] = True
+    assert np.array_equal(have, have.T) and full.npairs == 2 * half.npairs and not have.diagonal().any()
+    d = q[None, :, :3] - q[:, None, :3]
+    d -= np.round(d / np.array(box)) * np.array(box)
+    r2 = (d * d).sum(axis=2)
+    near = np.abs(r2 - rc * rc) < 1e-9
+    want = (r2 <= rc * rc) & ~np.eye(n, dtype=bool)
+    assert np.array_equal(have[~near], want[~near])
+
+    # float32, partners at rc (1 +- k ulp) across the low x face
+    L, nc = 30.0, 1500
+    centres = rng.uniform(0.0, L, size=(nc, 3))
+    centres[:, 0] = rng.uniform(0.0, 1.0, size=nc)
+    dvec = rng.normal(size=(nc, 3))
+    dvec[:, 0] = -np.abs(dvec[:, 0])
+    dvec /= np.linalg.norm(dvec, axis=1, keepdims=True)
+    scale = 1.0 + rng.integers(-6, 7, size=(nc, 1)) * 2.0 ** -23
+    q32 = np.zeros((2 * nc, 4), dtype=np.float32)
+    q32[:, :3] = np.concatenate([centres, np.mod(centres + dvec * rc * scale, L)]).astype(np.float32)
+    q32[:, :3] = np.minimum(q32[:, :3], np.nextafter(np.float32(L), np.float32(0)))
+    half, full = po.build_pbc(q32, rc, (L, L, L)), po.build_pbc_full(q32, rc, (L, L, L))
+    m = 2 * nc
+    rows = np.repeat(np.arange(m), np.diff(full.key_pointer))
+    up = full.sorted_list > rows
+    assert np.array_equal(full.sorted_list[up], half.sorted_list)
+    have = np.zeros((m, m), dtype=bool)
+    have[rows, full.sorted_list] = True
+    assert (have != have.T).any(), "pairs accepted in one direction only are what this mode's definition is about"

@@ -39,7 +39,11 @@ for case in range(cases):
     for rep in range(2):  # twice on the same handle
         nl.MakeNeighList(qd, n, sync=(rep == 0))
         nl.synchronize()
-        if full:
+        if full and pbc:  # minimum image: row i in the frame of particle i (not the symmetrised half list)
+            kp, lst, _ = (t.cpu().numpy() for t in nl.full_csr())
+            want = po.build_pbc_full(q, rc, box)
+            ok = np.array_equal(kp.astype(np.int64), want.key_pointer) and np.array_equal(canonical_csr(kp, lst), want.sorted_list)
+        elif full:
             kp, lst, _ = (t.cpu().numpy() for t in nl.full_csr())
             ok = int(kp[-1]) == 2 * ref.npairs
             if ok:
