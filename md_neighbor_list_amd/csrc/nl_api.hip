@@ -182,8 +182,13 @@ int launch_scan(nl_handle_t h, const int32_t* in, int64_t n, int32_t* out, int64
   }
   const int32_t nb = (int32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum);
+  if (nb <= SCAN_FUSED_MAX) {  // every block of the down-sweep adds up the block sums before it: one launch less
+    hipLaunchKernelGGL(k_scan_down<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
+                       total_split);
+    return NL_OK;
+  }
   hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, h->block_sum, nb, total);
-  hipLaunchKernelGGL(k_scan_down, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
+  hipLaunchKernelGGL(k_scan_down<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
                      total_split);
   return NL_OK;
 }

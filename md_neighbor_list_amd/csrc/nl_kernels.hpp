@@ -263,15 +263,28 @@ __global__ void __launch_bounds__(1024) k_scan_spine(int64_t* __restrict__ block
 }
 
 // out[i] = exclusive prefix (int32); out[n] = total.  Flags ST_INDEX_OVERFLOW when the total exceeds INT32_MAX.
+// FUSED (up to SCAN_FUSED_MAX blocks): block_off holds the RAW block sums of k_scan_reduce; every block adds up the
+// sums before it itself (<= 8 KiB of reads) and the last block publishes the grand total -- no spine launch.
+constexpr int SCAN_FUSED_MAX = 1024;
+template <bool FUSED>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __restrict__ in, int64_t n,
                                                              const int64_t* __restrict__ block_off,
-                                                             const int64_t* __restrict__ total,
+                                                             int64_t* __restrict__ total,
                                                              int32_t* __restrict__ out,
                                                              uint32_t* __restrict__ status,
                                                              uint32_t* __restrict__ total_split) {
   __shared__ int32_t wsum[SCAN_THREADS / WAVE];
+  __shared__ int64_t osum[SCAN_THREADS / WAVE];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_ITEMS;
+  int64_t my_off = 0;
+  if (FUSED) {
+    int64_t t = 0;
+    for (int32_t k = tid; k < (int32_t)blockIdx.x; k += SCAN_THREADS) t += block_off[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d, WAVE);
+    if (lane == 0) osum[w] = t;
+  }
   int32_t v[SCAN_ITEMS];
   load_items(in, n, base, v);
   int32_t s = 0;
@@ -282,7 +295,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
   __syncthreads();
   int32_t woff = 0;
   for (int k = 0; k < w; k++) woff += wsum[k];
-  int32_t run = (int32_t)block_off[blockIdx.x] + woff + inc - s;
+  if (FUSED) {
+#pragma unroll
+    for (int k = 0; k < SCAN_THREADS / WAVE; k++) my_off += osum[k];
+  } else {
+    my_off = block_off[blockIdx.x];
+  }
+  int32_t run = (int32_t)my_off + woff + inc - s;
   if (base + SCAN_ITEMS <= n) {
     int4* p = reinterpret_cast<int4*>(out + base);
 #pragma unroll
@@ -301,8 +320,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
       run += v[k];
     }
   }
-  if (blockIdx.x == 0 && tid == 0) {
-    const int64_t t = total[0];
+  if (FUSED ? (blockIdx.x == gridDim.x - 1 && tid == 0) : (blockIdx.x == 0 && tid == 0)) {
+    const int64_t t = FUSED ? my_off + block_off[blockIdx.x] : total[0];
+    if (FUSED) total[0] = t;
     out[n] = (int32_t)t;
     if (t > 2147483647LL) atomicOr(status, ST_INDEX_OVERFLOW);
     if (total_split) {  // the grand total next to the status word: one small device->host copy per build
