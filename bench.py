@@ -239,7 +239,7 @@ def main():
                         "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": round(gbs / copy_gbs, 4),
                         "traffic": _traffic_from_profiles(kname) if world == 1 else None,
                         "algorithmic_bytes_per_launch": b_search, "kernel_ms": round(kms, 4),
-                        "note": "VALU-issue bound, not HBM bound: 12 VALU + 4 SALU per 64 distance tests (DESIGN.md "
+                        "note": "VALU-issue bound, not HBM bound: 11.4 VALU + 3.7 SALU per 64 distance tests (DESIGN.md "
                                 "section 4); `build` gives the whole-build HBM fraction",
                         "stages_ms": {k: round(v, 4) for k, v in stages.items()}}
         b_build = n_total * vec_bytes + 4 * npairs + 4 * (n_total + 1) + 4 * n_total
