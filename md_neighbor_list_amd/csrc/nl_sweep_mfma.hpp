@@ -102,7 +102,7 @@ __device__ __forceinline__ float mf_join16(uint32_t p) {  // h + l back as fp32
 // staged tiles.
 // i_off: stream position of the cell's own first particle (the i-particles are part of their own stencil, so their
 // local coordinates and ids are already in LDS).
-template <bool F16 = false>
+template <bool F16 = false, bool FULL = false>
 __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx& c, MfmaLds& L, int lane,
                                         int32_t i_off, int32_t i0, int32_t res, int32_t ntiles) {
   const int kq = lane >> 4, lam = lane & 15;
@@ -166,7 +166,8 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const float av = acc[r];  // (bit_cast straight from the vector element picks element 0)
-      const uint32_t h = __float_as_uint(av) & (uint32_t)(gi[r] - gj);
+      // (full list: everyone in range but the row itself, whose bit is cleared after the loop: no id work per test)
+      const uint32_t h = FULL ? __float_as_uint(av) : __float_as_uint(av) & (uint32_t)(gi[r] - gj);
       bits[r] = __builtin_amdgcn_alignbit(bits[r], h, 31);  // (bits << 1) | (h >> 31)
     }
     return m;
@@ -184,7 +185,7 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
       const Pos<float> pi = mf_load_pos_blocking(a.sorted + c.ibeg + min(irow, c.ni - 1));
       const float dx = sub_rn(pj.x, pi.x), dy = sub_rn(pj.y, pi.y), dz = sub_rn(pj.z, pi.z);
       const float r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-      const bool want = !(r2 > a.rc2) && gi[r] < gj && jok && irow < c.ni;
+      const bool want = !(r2 > a.rc2) && (FULL ? gi[r] != pj.gid : gi[r] < gj) && jok && irow < c.ni;
       bits[r] = (bits[r] & ~(1u << pos)) | ((want ? 1u : 0u) << pos);
     }
     if (a.dbg & 8) atomicAdd(a.dbg_buf + 0, 1ull);
@@ -205,7 +206,7 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
     const float* pb = bp + res * MF_TILE;
     const int32_t* pg = gp + res * MF_TILE;
     float b0 = pb[0], b1 = pb[STRIDE];
-    int32_t g0 = pg[0], g1 = pg[STRIDE];
+    int32_t g0 = FULL ? 0 : pg[0], g1 = FULL ? 0 : pg[STRIDE];
     f32x4 acc0 = mma(b0), acc1 = mma(b1);
     for (int32_t s_ = 0; s_ < ns; s_ += 2) {
       pb += 2 * STRIDE, pg += 2 * STRIDE;
@@ -214,7 +215,7 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
       const int32_t ng0 = g0, ng1 = g1;
 #else
       const float nb0 = pb[0], nb1 = pb[STRIDE];
-      const int32_t ng0 = pg[0], ng1 = pg[STRIDE];
+      const int32_t ng0 = FULL ? 0 : pg[0], ng1 = FULL ? 0 : pg[STRIDE];
 #endif
       const bool two = s_ + 1 < ns;
       float m = process(acc0, g0, __builtin_huge_valf());
@@ -234,7 +235,11 @@ __device__ __forceinline__ void mf_unit(const SweepArgs<float>& a, const CellCtx
   for (int r = 0; r < 4; r++) {
     const int32_t irow = i0 + 4 * kq + r;
     // step s sits at bit ns - 1 - s (v_alignbit shifts left): reverse into bit s
-    const uint32_t w = ns > 0 ? __brev(bits[r]) >> (32 - ns) : 0u;
+    uint32_t w = ns > 0 ? __brev(bits[r]) >> (32 - ns) : 0u;
+    if (FULL) {  // the row's own particle (distance 0: always "in range") is staged at i_off + irow: tile, lane, step
+      const int32_t p_self = i_off + irow, t_self = p_self >> 4;
+      if ((t_self & 3) == res && (p_self & 15) == lam) w &= ~(1u << (t_self >> 2));
+    }
 #ifndef MF_ABL_NO_STORE
     if (irow < c.ni) mask_store(a.masks, (size_t)(c.ibeg + irow), res * 16 + lam, w);
 #endif
@@ -258,7 +263,7 @@ __device__ __forceinline__ void mf_stamp(const SweepArgs<float>& a, int tid, int
   }
 }
 
-template <bool F16>
+template <bool F16, bool FULL = false>
 __device__ __forceinline__ void mf_cell(const SweepArgs<float>& a) {
   __shared__ __attribute__((aligned(16))) MfmaLds L;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -270,8 +275,8 @@ __device__ __forceinline__ void mf_cell(const SweepArgs<float>& a) {
   if (c.total_j > MF_CAP || c.ni > MF_ROWS) {
     // stencil larger than one LDS batch, or a very full cell: the VALU search (same masks, same counts; cells of
     // several batches get counts only and are searched again by k_fill_masks)
-    cell_search<float, MODE_COUNT_MASKS, SweepCfg<float>::CAP, MF_WAVES>(a, c, reinterpret_cast<Pos<float>*>(L.comp), tid,
-                                                                         lane, wave);
+    cell_search<float, MODE_COUNT_MASKS, SweepCfg<float>::CAP, MF_WAVES, FULL>(a, c, reinterpret_cast<Pos<float>*>(L.comp),
+                                                                               tid, lane, wave);
     return;
   }
   // centre of the i-cell: the origin of the local coordinates (any point near the cell would do)
@@ -356,14 +361,14 @@ __device__ __forceinline__ void mf_cell(const SweepArgs<float>& a) {
     const bool row_far = lane < c.ni && mf_join16(__float_as_uint(L.comp[3 * MF_CSTR + i_off + lane])) >= 30000.0f;
     if (__builtin_amdgcn_ballot_w64(row_far) != 0) {
       __syncthreads();  // (rare) everyone has read its rows before the stream is staged again as positions
-      cell_search<float, MODE_COUNT_MASKS, SweepCfg<float>::CAP, MF_WAVES>(a, c, reinterpret_cast<Pos<float>*>(L.comp),
-                                                                           tid, lane, wave);
+      cell_search<float, MODE_COUNT_MASKS, SweepCfg<float>::CAP, MF_WAVES, FULL>(a, c, reinterpret_cast<Pos<float>*>(L.comp),
+                                                                                 tid, lane, wave);
       return;
     }
   }
   // one unit per (i-block, tile residue): wave w walks the i-blocks with residue w -- every wave of the workgroup
   // (one per SIMD) does the same number of steps
-  for (int32_t i0 = 0; i0 < c.ni; i0 += 16) mf_unit<F16>(a, c, L, lane, i_off, i0, wave, ntiles);
+  for (int32_t i0 = 0; i0 < c.ni; i0 += 16) mf_unit<F16, FULL>(a, c, L, lane, i_off, i0, wave, ntiles);
   mf_stamp(a, tid, 3, t_prev);  // search + word stores
   __syncthreads();
   mf_stamp(a, tid, 4, t_prev);  // barrier
@@ -373,5 +378,7 @@ __device__ __forceinline__ void mf_cell(const SweepArgs<float>& a) {
 
 __global__ void __launch_bounds__(MF_WAVES* WAVE, 6) k_sweep_mfma_f32(SweepArgs<float> a) { mf_cell<false>(a); }
 __global__ void __launch_bounds__(MF_WAVES* WAVE, 6) k_sweep_mfma_f16(SweepArgs<float> a) { mf_cell<true>(a); }
+// the full list (both directions): no id test per pair, the row's own bit is cleared at the end
+__global__ void __launch_bounds__(MF_WAVES* WAVE, 6) k_sweep_mfma_f16_full(SweepArgs<float> a) { mf_cell<true, true>(a); }
 
 }  // namespace nl

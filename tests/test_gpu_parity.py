@@ -548,3 +548,47 @@ def test_minimum_image_full_list_is_evaluated_in_the_row_frame():
             kp, lst = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
         assert np.array_equal(kp.astype(np.int64), want.key_pointer)
         assert np.array_equal(canonical_csr(kp, lst), want.sorted_list)
+
+
+def test_full_list_from_the_matrix_core_search(monkeypatch):
+    """NL_SWEEP_VARIANT=5 with NL_LIST_FULL: the f16 matrix-core search in its full-list form (no id test per pair, the
+    row's own bit cleared at the end) -- random boxes incl. particles on the box edge (VALU fall-back cells), and
+    partners at rc*(1 +- k ulp) (every one inside the band that is re-tested exactly)."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    monkeypatch.setenv("NL_SWEEP_VARIANT", "5")
+    rng = np.random.default_rng(55)
+    cases = []
+    for k in range(6):
+        rc = float(rng.uniform(1.5, 4.0))
+        mesh = rng.integers(4, 12, size=3)
+        box = tuple(float(m * rc * rng.uniform(1.0, 1.25)) for m in mesh)
+        n = int(int(mesh[0]) * int(mesh[1]) * int(mesh[2]) * rng.uniform(15.0, 40.0))
+        q = np.zeros((n, 4), dtype=np.float32)
+        q[:, :3] = rng.uniform(0.0, 1.0, size=(n, 3)) * np.array(box)
+        q[:40, :3] = np.round(q[:40, :3] / np.array(box)) * np.array(box)  # on the faces
+        q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=np.float32), np.float32(0)))
+        cases.append((q, rc, box))
+    rc, L, nc = 3.3, 40.0, 6000
+    centres = rng.uniform(4.0, L - 4.0, size=(nc, 3))
+    d = rng.normal(size=(nc, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    scale = 1.0 + rng.integers(-6, 7, size=(nc, 1)) * 2.0 ** -23
+    q = np.zeros((2 * nc, 4), dtype=np.float32)
+    q[:, :3] = np.concatenate([centres, centres + d * rc * scale]).astype(np.float32)
+    cases.append((q[rng.permutation(len(q))], rc, (L, L, L)))
+    used = 0
+    for q, rc, box in cases:
+        n = len(q)
+        want_kp, want_list, want_cnt = _full_from_half(_po().build(q, rc, box))
+        nl = NeighListGPU(rc, *box, dtype=torch.float32, full_list=True)
+        nl.Initialize(n)
+        nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+        used += int(nl.build_info()["mfma"])
+        kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr())
+        assert np.array_equal(cnt, want_cnt)
+        assert np.array_equal(kp.astype(np.int64), want_kp)
+        assert np.array_equal(canonical_csr(kp, lst), want_list)
+    assert used >= 4, "the matrix-core kernel must have been the one running"
