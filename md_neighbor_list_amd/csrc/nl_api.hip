@@ -66,7 +66,6 @@ struct nl_handle_s {
   bool bin_two_level = true;      // NL_BINNING=1 selects the atomic-rank path (k_hash/k_reorder)
   int32_t* base_sorted = nullptr;  // key_pointer of every sorted slot (persistent sweep, mask expansion)
   uint32_t* masks = nullptr;       // [n][64] hit bits of every sorted slot, between COUNT_MASKS and k_fill_masks
-  bool sweep_variant_forced = false;  // NL_SWEEP_VARIANT was given: no automatic choice per build
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps; 2: persistent LDS-DMA sweeps (fp32);
                                    // 3 (default): VALU COUNT keeping hit masks + mask expansion;
                                    // 4: as 3 with the fp32 COUNT on the matrix cores (k_sweep_mfma_f32; slower so far)
@@ -319,13 +318,10 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   h->b_full = h->list_kind == NL_LIST_FULL;
   // (the persistent and matrix-core variants implement the reference's open-box distances and the half list only)
   h->b_variant = (h->b_full || h->pbc) ? (h->sweep_variant >= 3 ? 3 : 1) : h->sweep_variant;
-  // Full list, open box: the f16 matrix-core search in its full-list form needs no id test per pair and is the faster
-  // COUNT pass where cells hold two or more 16-row blocks (cfg 2, 39 per cell: 272 against 308 us; 29 per cell: even;
-  // 19 per cell: 291 against 230).  Default for such builds from 33 particles per cell on (fp32; fp64 launches the
-  // VALU sweep); NL_SWEEP_VARIANT=3 / 5 force either.
-  if (h->b_full && !h->pbc &&
-      (h->sweep_variant_forced ? h->sweep_variant == 5 : (sizeof(T) == 4 && (double)n >= 33.0 * (double)ncl)))
-    h->b_variant = 5;
+  // Full list, open box: the f16 matrix-core search has a full-list form (no id test per pair), opt-in like the other
+  // matrix-core variants (NL_SWEEP_VARIANT=5): the north star of this path asks for a VALU search, and the default
+  // stays one.  Measured: COUNT 272 against 308 us at cfg 2 (39 particles per cell), even at 29, 291 against 230 at 19.
+  if (h->b_full && !h->pbc && h->sweep_variant == 5) h->b_variant = 5;
   h->b_use_masks = h->b_variant >= 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
   h->b_use_mfma = h->b_use_masks && h->b_variant >= 4 && sizeof(T) == 4;
   const int32_t nbp = (n + 255) / 256;
@@ -532,7 +528,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
-    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(5, std::max(1, atoi(v))), h->sweep_variant_forced = true;
+    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(5, std::max(1, atoi(v)));
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_DEBUG_FLAGS")) h->dbg_flags = atoi(v);
     if (const char* v = getenv("NL_DEBUG_WG_PER_CU")) h->dbg_wg_per_cu = std::max(1, atoi(v));
