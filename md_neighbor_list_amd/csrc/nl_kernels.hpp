@@ -590,10 +590,14 @@ constexpr int NSEG = 18;
 // particle t*64 + l is accepted (1 VALU per test, no scalar work); the 64 words of an i-particle go to
 // a.masks[(slot0 + k) * 64 + l] at the end (store_masks: only for cells whose stencil fits one LDS batch, which
 // also bounds t by CAP/64 <= 32).
-template <typename T, int MODE, int GC, bool FULL = false>
+// NOSELF (full list, COUNT_MASKS, the whole stream in one batch): "every j != i in range" is tested as "every j in
+// range" -- no id compare and no s_and per test -- and the row's own particle (distance 0: always in range), staged at
+// stream position self0 + k, is taken out of the word and of the count once at the end.
+template <typename T, int MODE, int GC, bool FULL = false, bool NOSELF = false>
 __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos<T>* tile, int32_t nj,
                                                 int32_t ntiles, int lane, const Pos<T>& pi_l, int32_t base_l,
-                                                int32_t slot0 = 0, bool store_masks = false) {
+                                                int32_t slot0 = 0, bool store_masks = false, int32_t self0 = 0) {
+  static_assert(!NOSELF || (FULL && MODE == MODE_COUNT_MASKS), "NOSELF is a form of the full-list COUNT_MASKS search");
   static_assert(SweepCfg<T>::CAP / WAVE <= 24, "one bit per j-tile in the 24-bit word a lane keeps (mask_store)");
   T xi[GC], yi[GC], zi[GC];
   int32_t gi[GC];
@@ -627,9 +631,10 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
       const T dx = sub_rn(pj.x, xi[k]), dy = sub_rn(pj.y, yi[k]), dz = sub_rn(pj.z, zi[k]);
       const T r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
       // half list: j is kept by the particle with the smaller id; full list: everyone but i itself
-      const bool in_range = !(r2 > a.rc2), upper = FULL ? pj.gid != gi[k] : pj.gid > gi[k];
+      const bool in_range = !(r2 > a.rc2), upper = NOSELF ? true : FULL ? pj.gid != gi[k] : pj.gid > gi[k];
       hit[k] = in_range && upper;
-      mask[k] = __builtin_amdgcn_ballot_w64(in_range) & __builtin_amdgcn_ballot_w64(upper);
+      mask[k] = NOSELF ? __builtin_amdgcn_ballot_w64(in_range)
+                       : __builtin_amdgcn_ballot_w64(in_range) & __builtin_amdgcn_ballot_w64(upper);
     }
 #pragma unroll
     for (int k = 0; k < GC; k++) {
@@ -669,7 +674,15 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   if (MODE == MODE_COUNT_MASKS) {
     if (store_masks) {
 #pragma unroll
-      for (int k = 0; k < GC; k++) mask_store(a.masks, (size_t)(slot0 + k), lane, __brev(bits[k]) >> (32 - ntiles));
+      for (int k = 0; k < GC; k++) {
+        uint32_t w = __brev(bits[k]) >> (32 - ntiles);
+        if (NOSELF && lane == ((self0 + k) & (WAVE - 1))) w &= ~(1u << ((self0 + k) >> 6));
+        mask_store(a.masks, (size_t)(slot0 + k), lane, w);
+      }
+    }
+    if (NOSELF) {
+#pragma unroll
+      for (int k = 0; k < GC; k++) cur[k] -= 1u;
     }
   }
   uint32_t mine = 0;
@@ -753,6 +766,16 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
   const int32_t ngroups = rounds * NW;
   const int32_t gsize = (ni + ngroups - 1) / ngroups;
 
+  // where the cell's own particles sit in the stream (NOSELF): in the (dz,dy) = (0,0) row, first or wrapped x-part
+  int32_t own = 0;
+  constexpr bool CAN_NOSELF = FULL && MODE == MODE_COUNT_MASKS;
+  if (CAN_NOSELF) {
+    const int32_t s4 = __builtin_amdgcn_readlane(c.seg_src, 4), l4 = __builtin_amdgcn_readlane(c.seg_len, 4);
+    const bool in4 = ibeg >= s4 && ibeg < s4 + l4;
+    own = in4 ? __builtin_amdgcn_readlane(c.seg_off, 4) + ibeg - s4
+              : __builtin_amdgcn_readlane(c.seg_off, 13) + ibeg - __builtin_amdgcn_readlane(c.seg_src, 13);
+  }
+
   for (int32_t batch = 0; batch < nbatch; batch++) {
     const int32_t win0 = batch * CAP;
     const int32_t nj = min(total_j - win0, CAP);
@@ -819,6 +842,19 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       // hit masks are kept only for single-batch cells (k_fill_masks re-searches the rest)
       const bool keep = nbatch == 1 && CAP == SweepCfg<T>::CAP;
       int32_t mine;  // lane k < gcount: hits of i-particle k in this batch
+      if constexpr (CAN_NOSELF) {
+        if (nbatch == 1) {  // (uniform) the row's own particle is in this, the only, batch
+          switch (gcount) {
+            case 1: mine = search_group<T, MODE, 1, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
+            case 2: mine = search_group<T, MODE, 2, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
+            case 3: mine = search_group<T, MODE, 3, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
+            case 4: mine = search_group<T, MODE, 4, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
+            default: mine = search_group<T, MODE, 5, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
+          }
+          if (lane < gcount) a.count[row_l] = mine;
+          continue;
+        }
+      }
       switch (gcount) {
         case 1: mine = search_group<T, MODE, 1, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
         case 2: mine = search_group<T, MODE, 2, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
