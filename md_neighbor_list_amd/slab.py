@@ -156,14 +156,18 @@ def exchange_ghosts(st: SlabState) -> None:
     lo_peer, hi_peer = (st.rank - 1) % st.world, (st.rank + 1) % st.world
     n0, n1 = st.n_rows, st.n_rows + st.n_ghost_lo
     in_w = st.q_all.shape[1] == 4  # ids travel inside the positions
-    q_lo = st.q_all[:n0].index_select(0, st.send_lo_idx)
-    q_hi = st.q_all[:n0].index_select(0, st.send_hi_idx)
+    # one gather for both layers (one small kernel per build instead of two): [bottom layer; top layer]
+    n_lo = st.send_lo_idx.numel()
+    if not hasattr(st, "_send_idx"):
+        st._send_idx = torch.cat([st.send_lo_idx, st.send_hi_idx])
+    packed = st.q_all[:n0].index_select(0, st._send_idx)
+    q_lo, q_hi = packed[:n_lo], packed[n_lo:]
     sends = [("send", q_lo, lo_peer), ("send", q_hi, hi_peer)]
     recv_lo = [("recv", st.q_all[n0:n1], lo_peer)]
     recv_hi = [("recv", st.q_all[n1:n1 + st.n_ghost_hi], hi_peer)]
     if not in_w:
-        g_lo = st.gid_all[:n0].index_select(0, st.send_lo_idx)
-        g_hi = st.gid_all[:n0].index_select(0, st.send_hi_idx)
+        g_packed = st.gid_all[:n0].index_select(0, st._send_idx)
+        g_lo, g_hi = g_packed[:n_lo], g_packed[n_lo:]
         sends = [("send", q_lo, lo_peer), ("send", g_lo, lo_peer), ("send", q_hi, hi_peer), ("send", g_hi, hi_peer)]
         recv_lo.append(("recv", st.gid_all[n0:n1], lo_peer))
         recv_hi.append(("recv", st.gid_all[n1:n1 + st.n_ghost_hi], hi_peer))
