@@ -592,3 +592,38 @@ def test_full_list_from_the_matrix_core_search(monkeypatch):
         assert np.array_equal(kp.astype(np.int64), want_kp)
         assert np.array_equal(canonical_csr(kp, lst), want_list)
     assert used >= 4, "the matrix-core kernel must have been the one running"
+
+
+@pytest.mark.parametrize("variant", [3, 5])
+def test_full_list_at_baseline_size(variant, monkeypatch):
+    """BASELINE config 2 (N = 1 048 576) as a FULL list -- the VALU search without the id test (own bit cleared at the
+    end) and the opt-in matrix-core form: twice the stored pair count, every row symmetric on a sample, and the upper
+    part (j > i) of the list hashes to the stored answer of the half list."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+    from oracle import pyoracle as po
+
+    monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))["u1M_rho1_f32"]
+    q, box = inputs.uniform_box(ka["n"], 1.0, np.float32)
+    n = len(q)
+    nl = NeighListGPU(ka["rc"], *box, dtype=torch.float32, full_list=True)
+    nl.Initialize(n)
+    nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+    assert bool(nl.build_info()["mfma"]) == (variant == 5)
+    kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr())
+    assert int(kp[-1]) == 2 * ka["npairs"] == len(lst)
+    assert np.array_equal(np.diff(kp), cnt)
+    rows = np.repeat(np.arange(n, dtype=np.int32), cnt)
+    assert not np.any(lst == rows)  # no self pairs
+    up = lst > rows
+    nop = np.bincount(rows[up], minlength=n).astype(np.int32)
+    hk = np.concatenate([[0], np.cumsum(nop)]).astype(np.int64)
+    assert int(nop.max()) == ka["nop_max"]
+    assert f"{po.HalfList(nop, hk, lst[up]).hash():016x}" == ka["hash"]
+    # symmetry on a sample of rows: i in row j for every j in row i
+    rng = np.random.default_rng(11)
+    for i in rng.integers(0, n, size=200):
+        for j in lst[kp[i]:kp[i + 1]][:8]:
+            assert i in lst[kp[j]:kp[j + 1]]
