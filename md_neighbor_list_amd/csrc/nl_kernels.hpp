@@ -910,9 +910,10 @@ k_sweep_count_masks_f32(SweepArgs<float> a) {
 // ------------------------------------------------------------------------------------------ list from masks
 // a8 + a9 without a second distance sweep: COUNT_MASKS left, for every i-particle (sorted slot), 64 words whose
 // bits say which particles of its cell's staged stencil stream were accepted.  This kernel re-stages only the ids
-// of the stream (4 B per particle) and expands the bits into the final CSR rows, one row per wave at a time:
-// lane l owns word l, a DPP prefix sum of the popcounts gives its offset inside the row, and it writes its set bits
-// one by one (bit t -> staged particle t*64 + l: LDS reads of one instruction always hit 64 different banks).
+// of the stream (4 B per particle, LDS-DMA from the compact sorted_gid) and expands the bits into the final CSR rows,
+// four rows per wave at a time: lane l owns word l, a DPP prefix sum of the popcounts gives its offset inside the
+// row, and it takes its set bits one by one (bit t -> staged particle t*64 + l: LDS reads of one instruction always
+// hit 64 different banks) into a per-wave LDS copy of the row, which then leaves as runs of 64 consecutive entries.
 // Cells whose stencil needed several LDS batches have no masks: they are searched again here, exactly as
 // k_sweep<FILL> does.
 __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan over all 64 lanes
@@ -936,7 +937,6 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
   constexpr int EW = EXPAND_WAVES;
   constexpr int EXPAND_RMAX = EXPAND_RMAX_OF<FULL>;
-  // 5 KiB: ids only, so many workgroups per CU keep enough loads in flight
   // One LDS array (a second __shared__ object next to an LDS-DMA target makes hipcc drain the DMA before every
   // ds_read): the ids of the stencil stream (4.5 KiB) + per wave four rows being put together.
   __shared__ __attribute__((aligned(32))) int32_t lds[CAP + EW * 4 * EXPAND_RMAX];
