@@ -83,6 +83,13 @@ int nl_set_capacity(nl_handle_t h, int64_t max_pairs);
 enum nl_list_kind { NL_LIST_HALF = 0, NL_LIST_FULL = 1 };
 int nl_set_list_kind(nl_handle_t h, int kind);
 
+/* Launch mode of asynchronous builds ("capture launch-bound inner loops in hipGraphs").  on != 0:
+ * a build is captured once into a hipGraph (memset, the kernels, the 80-byte result copy) and replayed on the caller's
+ * stream by later builds with the same arguments; any change of an argument, of the list kind / periodic mode or of a
+ * buffer (growth, nl_initialize) captures again.  Pays on small systems, where a build is ~11 dependent launches
+ * (N = 4096: see DESIGN.md); off by default.  Also NL_GRAPH=1 in the environment. */
+int nl_set_graph(nl_handle_t h, int on);
+
 /* Distances across the periodic faces.  0 (default) = the reference: the 27-cell stencil wraps cell indices but the
  * distance is taken between the coordinates as given (neighlist_cpu.hpp:107-132,219-223), i.e. an open box.
  * 1 = minimum image (not in the reference): a stencil cell reached through a periodic face

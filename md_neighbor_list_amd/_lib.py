@@ -23,6 +23,7 @@ PROTOTYPES = {
     "nl_set_capacity": (C.c_int, [_P, _I64]),
     "nl_set_list_kind": (C.c_int, [_P, C.c_int]),
     "nl_set_periodic": (C.c_int, [_P, C.c_int]),
+    "nl_set_graph": (C.c_int, [_P, C.c_int]),
     "nl_destroy": (C.c_int, [_P]),
     "nl_make_list": (C.c_int, [_P, _P, _I32, _I32, _P, C.c_int]),
     "nl_make_list_slab": (C.c_int, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, C.c_int]),

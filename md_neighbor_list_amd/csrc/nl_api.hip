@@ -91,6 +91,24 @@ struct nl_handle_s {
 
   HostResult* host = nullptr;
   hipStream_t own_stream = nullptr;
+  // NL_GRAPH=1 / nl_set_graph: asynchronous builds are replayed from a captured hipGraph (one graph per argument set;
+  // re-captured when an argument or any buffer changes).  Saves launch overhead on small systems.
+  bool use_graph = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  struct GraphKey {
+    const void* q = nullptr;
+    const int32_t* gid = nullptr;
+    int32_t stride = 0, n_rows = 0, n = 0, z_lo = 0, mzl = 0, slab = 0, list_kind = 0, pbc = 0;
+    int64_t capacity = 0;
+    uint64_t epoch = 0;
+    bool operator==(const GraphKey& o) const {
+      return q == o.q && gid == o.gid && stride == o.stride && n_rows == o.n_rows && n == o.n && z_lo == o.z_lo &&
+             mzl == o.mzl && slab == o.slab && list_kind == o.list_kind && pbc == o.pbc && capacity == o.capacity &&
+             epoch == o.epoch;
+    }
+  } graph_key;
+  uint64_t buffers_epoch = 1;  // bumped by every (re)allocation
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[NL_NUM_STAGES + 1] = {};
 
@@ -127,6 +145,7 @@ int fail(nl_handle_t h, int code) {
 }
 
 template <typename P> int dev_alloc(nl_handle_t h, P** p, size_t bytes) {
+  h->buffers_epoch++;  // a captured graph holds the old pointers
   if (*p) (void)hipFree(*p);
   *p = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes ? bytes : 16);
@@ -530,6 +549,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(5, std::max(1, atoi(v)));
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
+    if (const char* v = getenv("NL_GRAPH")) h->use_graph = atoi(v) != 0;
     if (const char* v = getenv("NL_DEBUG_FLAGS")) h->dbg_flags = atoi(v);
     if (const char* v = getenv("NL_DEBUG_WG_PER_CU")) h->dbg_wg_per_cu = std::max(1, atoi(v));
     if (const char* v = getenv("NL_DEBUG_LDS_PAD")) h->dbg_lds_pad = std::max(0, atoi(v));
@@ -549,6 +569,8 @@ int nl_destroy(nl_handle_t h) {
   if (h->host) (void)hipHostFree(h->host);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) (void)hipGraphDestroy(h->graph);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return NL_OK;
@@ -631,6 +653,12 @@ int nl_set_list_kind(nl_handle_t h, int kind) {
   return NL_OK;
 }
 
+int nl_set_graph(nl_handle_t h, int on) {
+  if (!h) return NL_ERR_ARG;
+  h->use_graph = on != 0;
+  return NL_OK;
+}
+
 int nl_set_capacity(nl_handle_t h, int64_t max_pairs) {
   if (!h || max_pairs < 0) return fail(h, NL_ERR_ARG);
   HIPCHK(h, hipSetDevice(h->device));
@@ -677,10 +705,37 @@ int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const 
   h->built = false;
   h->t_valid = false;
   h->n = n, h->n_rows = n_rows;
-  int rc = dispatch_build(h, q_dev, q_stride, gid_dev, n_rows, n, z_lo, mzl, slab, s, nullptr);
-  if (rc) return rc;
-  rc = enqueue_result_copy(h, s);
-  if (rc) return rc;
+  int rc;
+  if (h->use_graph) {
+    nl_handle_s::GraphKey key;
+    key.q = q_dev, key.gid = gid_dev, key.stride = q_stride, key.n_rows = n_rows, key.n = n, key.z_lo = z_lo, key.mzl = mzl;
+    key.slab = slab, key.list_kind = h->list_kind, key.pbc = h->pbc ? 1 : 0, key.capacity = h->capacity;
+    key.epoch = h->buffers_epoch;
+    if (!h->graph_exec || !(key == h->graph_key)) {
+      if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec), h->graph_exec = nullptr;
+      if (h->graph) (void)hipGraphDestroy(h->graph), h->graph = nullptr;
+      // captured on the private stream (the null stream cannot be captured); replayed on the caller's stream
+      HIPCHK(h, hipStreamBeginCapture(h->own_stream, hipStreamCaptureModeRelaxed));
+      rc = dispatch_build(h, q_dev, q_stride, gid_dev, n_rows, n, z_lo, mzl, slab, h->own_stream, nullptr);
+      if (!rc) rc = enqueue_result_copy(h, h->own_stream);
+      hipGraph_t g = nullptr;
+      const hipError_t e = hipStreamEndCapture(h->own_stream, &g);
+      if (rc) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+      }
+      HIPCHK(h, e);
+      h->graph = g;
+      HIPCHK(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+      h->graph_key = key;
+    }
+    HIPCHK(h, hipGraphLaunch(h->graph_exec, s));
+  } else {
+    rc = dispatch_build(h, q_dev, q_stride, gid_dev, n_rows, n, z_lo, mzl, slab, s, nullptr);
+    if (rc) return rc;
+    rc = enqueue_result_copy(h, s);
+    if (rc) return rc;
+  }
   h->last_stream = s;
   h->pending = true;
   if (sync) return finish(h, true);

@@ -95,6 +95,10 @@ class NeighListGPU:
     def set_capacity(self, max_pairs):
         check(self._lib.nl_set_capacity(self._h, int(max_pairs)), "nl_set_capacity")
 
+    def set_graph(self, on: bool = True):
+        """Replay asynchronous builds from a captured hipGraph (nl_set_graph): saves launch overhead on small systems."""
+        check(self._lib.nl_set_graph(self._h, 1 if on else 0), "nl_set_graph")
+
     def set_periodic(self, minimum_image=True):
         """Minimum-image distances across the periodic faces (nl_set_periodic).  The reference, and the default here,
         wrap the cell stencil but measure distances in an open box."""

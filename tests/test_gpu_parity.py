@@ -627,3 +627,54 @@ def test_full_list_at_baseline_size(variant, monkeypatch):
     for i in rng.integers(0, n, size=200):
         for j in lst[kp[i]:kp[i + 1]][:8]:
             assert i in lst[kp[j]:kp[j + 1]]
+
+
+def test_graph_replay_builds_the_same_lists():
+    """nl_set_graph(1): asynchronous builds replayed from a captured hipGraph -- new positions in the same buffer
+    (replay), another particle count and another buffer (capture again), a list that has to grow (capture again), a
+    synchronous build in between; every result against the oracle."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    rng = np.random.default_rng(8)
+    rc, box = 3.0, (36.0, 33.0, 30.0)
+    n = 30000
+    nl = NeighListGPU(rc, *box, dtype=torch.float32)
+    nl.Initialize(n)
+    nl.set_graph(True)
+    buf = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+
+    def check(q, t, m):
+        ref = _po().build(q, rc, box)
+        kp, sl = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
+        assert int(kp[-1]) == ref.npairs
+        assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+
+    for step in range(4):  # same buffer, same count: one capture, three replays
+        q = np.zeros((n, 4), dtype=np.float32)
+        q[:, :3] = rng.uniform(0.0, 1.0, size=(n, 3)) * np.array(box)
+        q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=np.float32), np.float32(0)))
+        buf.copy_(torch.from_numpy(q))
+        nl.MakeNeighList(buf, n, sync=False)
+        nl.synchronize()
+        check(q, buf, n)
+    m = 21000  # fewer particles, another buffer
+    q2 = np.zeros((m, 4), dtype=np.float32)
+    q2[:, :3] = rng.uniform(0.0, 1.0, size=(m, 3)) * np.array(box)
+    q2[:, :3] = np.minimum(q2[:, :3], np.nextafter(np.array(box, dtype=np.float32), np.float32(0)))
+    t2 = torch.from_numpy(q2).cuda()
+    nl.MakeNeighList(t2, m, sync=False)
+    nl.synchronize()
+    check(q2, t2, m)
+    nl.MakeNeighList(t2, m, sync=True)  # synchronous build through the same graph
+    check(q2, t2, m)
+    # a clustered configuration overflows the list: the synchronous build grows it (new buffer: capture again)
+    q3 = q2.copy()
+    q3[:, :3] = q3[:, :3] * 0.45
+    t3 = torch.from_numpy(q3).cuda()
+    nl.MakeNeighList(t3, m, sync=True)
+    check(q3, t3, m)
+    nl.MakeNeighList(t3, m, sync=False)
+    nl.synchronize()
+    check(q3, t3, m)
