@@ -357,11 +357,14 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
       hipLaunchKernelGGL((k_bin_rows<T>), dim3(h->bin_blocks), dim3(BIN_THREADS), 0, s, q, stride, n, h->bin_chunk, g, nrows,
                          h->row_count, h->blk_base, h->status);
     if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_CELL_SCAN], s));
-    if (int rc = launch_scan(h, h->row_count, nrows, h->row_start, h->totals, s)) return rc;
+    // (no scan launch: every block of k_bin_scatter scans the row totals itself and block 0 publishes row_start)
+    if (n <= 0) {
+      if (int rc = launch_scan(h, h->row_count, nrows, h->row_start, h->totals, s)) return rc;
+    }
     if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_REORDER], s));
     if (n > 0)
       hipLaunchKernelGGL((k_bin_scatter<T>), dim3(h->bin_blocks), dim3(BIN_THREADS), 0, s, q, stride, gid, n, h->bin_chunk, g,
-                         nrows, h->row_start, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row);
+                         nrows, h->row_count, h->row_start, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row);
     hipLaunchKernelGGL((k_bin_cells<T>), dim3(nrows), dim3(256), 0, s, g, nrows, h->row_start,
                        static_cast<const Pos<T>*>(h->tmp_pos), h->tmp_row, h->cell_start, static_cast<Pos<T>*>(h->sorted),
                        h->sorted_row, h->sorted_gid);

@@ -415,12 +415,39 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_rows(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict__ q, int32_t stride,
                                                              const int32_t* __restrict__ gid, int32_t n, int32_t chunk,
-                                                             Grid<T> g, int32_t nrows, const int32_t* __restrict__ row_start,
+                                                             Grid<T> g, int32_t nrows, const int32_t* __restrict__ row_count,
+                                                             int32_t* __restrict__ row_start,
                                                              const int32_t* __restrict__ blk_base, Pos<T>* __restrict__ tmp,
                                                              int32_t* __restrict__ tmp_row) {
   __shared__ int32_t cursor[BIN_MAX_ROWS];
-  const int tid = threadIdx.x;
-  for (int32_t r = tid; r < nrows; r += BIN_THREADS) cursor[r] = row_start[r] + blk_base[(size_t)blockIdx.x * nrows + r];
+  __shared__ int32_t wsum[BIN_THREADS / WAVE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // Every block scans the R row totals itself (a few thousand adds) instead of waiting for a scan kernel: one
+  // dependent launch less per build.  Thread t owns a run of K consecutive rows; block 0 publishes row_start for
+  // k_bin_cells.
+  {
+    const int32_t K = (nrows + BIN_THREADS - 1) / BIN_THREADS;
+    const int32_t b = min(tid * K, nrows), e = min(b + K, nrows);
+    int32_t ssum = 0;
+    for (int32_t i = b; i < e; i++) ssum += row_count[i];
+    const int32_t inc = wave_incl_scan(ssum, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int32_t woff = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < BIN_THREADS / WAVE; k++) {
+      const int32_t v = wsum[k];
+      woff += k < w ? v : 0;
+      all += v;
+    }
+    int32_t run = woff + inc - ssum;
+    for (int32_t i = b; i < e; i++) {
+      cursor[i] = run + blk_base[(size_t)blockIdx.x * nrows + i];
+      if (blockIdx.x == 0) row_start[i] = run;
+      run += row_count[i];
+    }
+    if (blockIdx.x == 0 && tid == 0) row_start[nrows] = all;
+  }
   __syncthreads();
   const int32_t beg = blockIdx.x * chunk, end = min(beg + chunk, n);
   for (int32_t i = beg + tid; i < end; i += BIN_THREADS) {

@@ -4,7 +4,9 @@ times from HIP events (what the kernels take): the difference is launch overhead
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from md_neighbor_list_amd import NeighListGPU, inputs
+from md_neighbor_list_amd import NeighListGPU, inputs, _lib
+if os.environ.get("NL_LIB"):  # A/B another build of the library
+    _lib.LIB_PATH = os.path.abspath(os.environ["NL_LIB"])
 for n in (4096, 32768, 119164, 262144, 1 << 20):
     q, box = inputs.uniform_box(n, 1.0, np.float32)
     qd = torch.from_numpy(q).cuda()
