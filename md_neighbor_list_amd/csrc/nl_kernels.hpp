@@ -378,6 +378,7 @@ __global__ void __launch_bounds__(1024) k_scan_small(const int32_t* __restrict__
 //                  particles are placed in cell order into sorted[] / sorted_row[].
 // The cell of a particle is the reference's (local_cell above); x-cell and row are its two factors.
 constexpr int BIN_THREADS = 1024;
+constexpr int BIN_UNROLL = 4;  // particles per thread whose loads are in flight together (k_bin_rows, k_bin_scatter)
 constexpr int BIN_MAX_ROWS = 12288;  // 48 KiB of LDS counters
 constexpr int BIN_MAX_MX = 4096;
 
@@ -390,20 +391,28 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_rows(const T* __restrict__ 
   for (int32_t r = tid; r < nrows; r += BIN_THREADS) hist[r] = 0;
   __syncthreads();
   const int32_t beg = blockIdx.x * chunk, end = min(beg + chunk, n);
-  for (int32_t i = beg + tid; i < end; i += BIN_THREADS) {
-    T x, y, z;
-    load_xyz(q, stride, i, x, y, z);
-    int32_t lz = 0, row = 0;
-    const int32_t c = local_cell(g, x, y, z, &lz, &row);
-    if (c < 0) {
-      atomicOr(status, c == -1 ? ST_OUT_OF_BOX : ST_DOMAIN);
-      continue;
+  // BIN_UNROLL particles per thread and trip, all loads first: one memory round trip per trip instead of one per
+  // particle (a chunk is 4 particles per thread).
+  for (int32_t i0 = beg + tid; i0 < end; i0 += BIN_UNROLL * BIN_THREADS) {
+    T x[BIN_UNROLL], y[BIN_UNROLL], z[BIN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BIN_UNROLL; u++) load_xyz(q, stride, min(i0 + u * BIN_THREADS, end - 1), x[u], y[u], z[u]);
+#pragma unroll
+    for (int u = 0; u < BIN_UNROLL; u++) {
+      const int32_t i = i0 + u * BIN_THREADS;
+      if (i >= end) break;
+      int32_t lz = 0, row = 0;
+      const int32_t c = local_cell(g, x[u], y[u], z[u], &lz, &row);
+      if (c < 0) {
+        atomicOr(status, c == -1 ? ST_OUT_OF_BOX : ST_DOMAIN);
+        continue;
+      }
+      if (g.slab) {
+        const bool in_owned_layer = lz >= 1 && lz < g.mzl - 1;
+        if (in_owned_layer != (i < g.n_rows)) atomicOr(status, ST_DOMAIN);
+      }
+      atomicAdd(&hist[row], 1);
     }
-    if (g.slab) {
-      const bool in_owned_layer = lz >= 1 && lz < g.mzl - 1;
-      if (in_owned_layer != (i < g.n_rows)) atomicOr(status, ST_DOMAIN);
-    }
-    atomicAdd(&hist[row], 1);
   }
   __syncthreads();
   for (int32_t r = tid; r < nrows; r += BIN_THREADS) {
@@ -450,27 +459,39 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
   }
   __syncthreads();
   const int32_t beg = blockIdx.x * chunk, end = min(beg + chunk, n);
-  for (int32_t i = beg + tid; i < end; i += BIN_THREADS) {
-    T x, y, z;
-    load_xyz(q, stride, i, x, y, z);
-    int32_t lz = 0, row = 0;
-    T sh[3];
-    const int32_t c = local_cell(g, x, y, z, &lz, &row, sh);
-    if (c < 0) continue;
-    const int32_t dst = atomicAdd(&cursor[row], 1);
-    Pos<T> p;
-    p.x = x, p.y = y, p.z = z;
-    // (minimum-image mode: x keeps its value until k_bin_cells has derived the x-cell from it)
-    if (g.pbc) p.y = add_rn(y, sh[1]), p.z = add_rn(z, sh[2]);
-    if (gid == reinterpret_cast<const int32_t*>(1)) {  // NL_GID_IN_W: the id travels in the w component of the Vec
-      if constexpr (sizeof(T) == 4) p.gid = __float_as_int(q[(size_t)i * 4 + 3]);
-      else p.gid = (int32_t)__double_as_longlong(q[(size_t)i * 4 + 3]);
-    } else {
-      p.gid = gid ? gid[i] : i;
+  const bool gid_in_w = gid == reinterpret_cast<const int32_t*>(1);  // NL_GID_IN_W: the id travels in the w component
+  for (int32_t i0 = beg + tid; i0 < end; i0 += BIN_UNROLL * BIN_THREADS) {  // all loads of a trip first (see k_bin_rows)
+    T x[BIN_UNROLL], y[BIN_UNROLL], z[BIN_UNROLL];
+    int32_t id[BIN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BIN_UNROLL; u++) {
+      const int32_t i = min(i0 + u * BIN_THREADS, end - 1);
+      load_xyz(q, stride, i, x[u], y[u], z[u]);
+      if (gid_in_w) {
+        if constexpr (sizeof(T) == 4) id[u] = __float_as_int(q[(size_t)i * 4 + 3]);
+        else id[u] = (int32_t)__double_as_longlong(q[(size_t)i * 4 + 3]);
+      } else {
+        id[u] = gid ? gid[i] : i;
+      }
     }
-    if constexpr (sizeof(T) == 8) p.row = i;
-    tmp[dst] = p;
-    tmp_row[dst] = i;
+#pragma unroll
+    for (int u = 0; u < BIN_UNROLL; u++) {
+      const int32_t i = i0 + u * BIN_THREADS;
+      if (i >= end) break;
+      int32_t lz = 0, row = 0;
+      T sh[3];
+      const int32_t c = local_cell(g, x[u], y[u], z[u], &lz, &row, sh);
+      if (c < 0) continue;
+      const int32_t dst = atomicAdd(&cursor[row], 1);
+      Pos<T> p;
+      p.x = x[u], p.y = y[u], p.z = z[u];
+      // (minimum-image mode: x keeps its value until k_bin_cells has derived the x-cell from it)
+      if (g.pbc) p.y = add_rn(y[u], sh[1]), p.z = add_rn(z[u], sh[2]);
+      p.gid = id[u];
+      if constexpr (sizeof(T) == 8) p.row = i;
+      tmp[dst] = p;
+      tmp_row[dst] = i;
+    }
   }
 }
 
