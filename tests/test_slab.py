@@ -1,4 +1,4 @@
-"""Multi-process tests of the slab decomposition: world_size 2 and 3 over gloo.
+"""Multi-process tests of the slab decomposition: world_size 2, 3 and 8 over gloo.
 CPU: decomposition + ghost exchange + ownership rule, per-rank build emulated by the oracle.
 GPU: the same with the real nl_make_list_slab on every rank (ranks share the one GPU of the test box)."""
 import numpy as np
@@ -39,6 +39,7 @@ def test_z_layer_matches_oracle_hash():
     (2, (4000, (12.0, 12.0, 17.0), 3.3, "float32", 73)),   # 5 layers: 3 + 2
     (2, (6000, (14.0, 14.0, 20.0), 3.3, "float32", 74, [2, 3])),  # layers 2 and 3 empty: zero-size ghost messages
     (3, (9000, (13.5, 15.0, 30.0), 3.3, "float32", 75, [0, 5])),  # empty layers at a slab top and at the box bottom
+    (8, (20000, (12.0, 12.0, 66.5), 3.3, "float32", 181)),  # the world size of the scaling run: 20 layers, 3+3+3+3+2+2+2+2
 ])
 def test_slab_union_equals_global_list_cpu(world, case):
     res = run(world, "oracle", case)
