@@ -120,6 +120,23 @@ def _traffic_from_profiles(kernel):
         return None
 
 
+def _reference_pairs(n_total, density, dtype, got):
+    """The pair count of this box from the compiled reference (tests/golden/known_answers.json, written by
+    oracle/gen_golden.py --big; a committed fixture, nothing under oracle/ runs here): "ok" when the build (the union
+    over ranks for N > 1) found exactly that many pairs, the two numbers otherwise, None when no answer is stored."""
+    try:
+        ka = json.load(open(os.path.join(ROOT, "tests", "golden", "known_answers.json")))
+    except Exception:
+        return None
+    if n_total % (1 << 20):
+        return None
+    key = f"u{n_total >> 20}M_rho{'1' if density == 1.0 else '05'}_{dtype}"
+    if key not in ka:
+        return None
+    want = int(ka[key]["npairs"])
+    return "ok" if want == int(got) else {"got": int(got), "reference": want}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,6 +279,7 @@ def main():
                                    f"{'fp32 float4' if args.dtype == 'f32' else 'fp64 double4'} positions, half list "
                                    f"(CSR in original particle order), mesh {mesh[0]}x{mesh[1]}x{mesh[2]}",
                        "n_particles": n_total, "half_pairs": npairs,
+                       "half_pairs_reference": _reference_pairs(n_total, density, args.dtype, npairs),
                        "decomposition": "none" if world == 1 else f"{world} z-slabs + 1-cell ghost layers (p2p)"},
             "build": {"algorithmic_bytes": b_build, "achieved_GBs": round(build_gbs, 1),
                       "frac_of_hbm_peak": round(build_gbs / HBM_PEAK_GBS, 4)},

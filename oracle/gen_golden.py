@@ -94,7 +94,7 @@ def main():
         print(f"N={len(q):5d} mesh={mesh} P={h.npairs:7d} hash={h.hash():016x} dup={dup}")
 
 
-def big():
+def big(only=None):
     """Known answers at the BASELINE sizes (too big to store as lists): pair count, pair-set hash, a checksum of
     number_of_partners, its maximum.  From the compiled reference (-DLOOP_FUSION build with pinned flags)."""
     import json
@@ -105,10 +105,16 @@ def big():
         ("u1M_rho1_f64", lambda: inputs.uniform_box(1 << 20, 1.0, np.float64), 3.3),
         ("u1M_rho05_f32", lambda: inputs.uniform_box(1 << 20, 0.5, np.float32), 3.3),  # BASELINE config 3
         ("u1M_rho05_f64", lambda: inputs.uniform_box(1 << 20, 0.5, np.float64), 3.3),
+        # the weak-scaling boxes of bench.py --gpus 2 / 4 / 8 (N x 1 048 576 particles at rho = 1)
+        ("u2M_rho1_f32", lambda: inputs.uniform_box(2 << 20, 1.0, np.float32), 3.3),
+        ("u4M_rho1_f32", lambda: inputs.uniform_box(4 << 20, 1.0, np.float32), 3.3),
+        ("u8M_rho1_f32", lambda: inputs.uniform_box(8 << 20, 1.0, np.float32), 3.3),
         ("fcc_L50_rho1_f64", lambda: inputs.fcc_box(1.0, 50.0, np.float64), 3.3),       # the README point
         ("fcc_L50_rho05_f64", lambda: inputs.fcc_box(0.5, 50.0, np.float64), 3.3),
         ("fcc_L50_rho1_f32", lambda: inputs.fcc_box(1.0, 50.0, np.float32), 3.3),
     ):
+        if only and name not in only:
+            continue
         q, box = gen()
         h = po.ref_build(q, rc, box, "fused")[0]
         nop = h.number_of_partners.astype(np.int64)
@@ -117,12 +123,18 @@ def big():
             "nop_max": int(nop.max()), "nop_weighted_sum": int((nop * (np.arange(len(nop)) % 1000003)).sum()),
         }
         print(name, out[name], flush=True)
-    with open(os.path.join(OUT, "known_answers.json"), "w") as f:
+    path = os.path.join(OUT, "known_answers.json")
+    if only and os.path.exists(path):  # merge a subset into the stored answers
+        old = json.load(open(path))
+        old.update(out)
+        out = old
+    with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    if "--big" in sys.argv:
-        big()
+    if "--big" in sys.argv:  # optionally: --big name,name  (only those entries, merged into the stored file)
+        k = sys.argv.index("--big")
+        big(set(sys.argv[k + 1].split(",")) if len(sys.argv) > k + 1 else None)
     else:
         main()

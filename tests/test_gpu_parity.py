@@ -678,3 +678,25 @@ def test_graph_replay_builds_the_same_lists():
     nl.MakeNeighList(t3, m, sync=False)
     nl.synchronize()
     check(q3, t3, m)
+
+
+@pytest.mark.parametrize("key", ["u2M_rho1_f32", "u8M_rho1_f32"])
+def test_weak_scaling_boxes_on_one_gpu(key):
+    """The boxes of bench.py --gpus 2 / 8 (N x 1 048 576 particles) built on ONE GPU against the compiled reference's
+    answers for them: pair count, the checksum and the maximum of number_of_partners -- the numbers the multi-GPU
+    bench line is compared with (`half_pairs_reference`).  No list download (2.5 GB at 8 M)."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))[key]
+    q, box = inputs.uniform_box(ka["n"], 1.0, np.float32)
+    nl = NeighListGPU(ka["rc"], *box, dtype=torch.float32)
+    nl.Initialize(len(q))
+    nl.MakeNeighList(torch.from_numpy(q).cuda(), len(q))
+    assert nl.half_number_of_pairs() == ka["npairs"]
+    nop = nl.half_number_of_partners().cpu().numpy().astype(np.int64)
+    assert int(nop.max()) == ka["nop_max"]
+    assert int((nop * (np.arange(len(nop)) % 1000003)).sum()) == ka["nop_weighted_sum"]
+    kp = nl.key_pointer().cpu().numpy()
+    assert int(kp[-1]) == ka["npairs"] and np.array_equal(np.diff(kp), nop)
