@@ -128,6 +128,18 @@ int nl_make_list(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_t n, 
 int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
                       int32_t n, int32_t z_lo, int32_t z_hi, void* stream, int sync);
 
+/* The same build in two calls, so that the halo exchange overlaps its first part: _begin enqueues what needs only
+ * the OWNED particles q[0, n_rows) -- the binning of the owned layers, about a tenth of the build -- and may be called
+ * while the ghost rows q[n_rows, n) are still being received; _finish (same stream, after the caller has made that
+ * stream wait for the exchange) enqueues the rest: the binning of the ghosts, the search, the scan, the expansion.
+ * n_ghost_lo = how many of the ghosts lie in the lower neighbour layer (z_lo - 1): the owned particles are placed
+ * behind them in the cell-sorted array before any ghost has been seen, so the number is part of the call; it is
+ * verified when the ghosts are binned (NL_ERR_DOMAIN).  The result is the one of nl_make_list_slab.  Builds that
+ * have nothing to overlap (single rank; NL_BINNING=1) do all their work in _finish. */
+int nl_make_list_slab_begin(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
+                            int32_t n, int32_t n_ghost_lo, int32_t z_lo, int32_t z_hi, void* stream);
+int nl_make_list_slab_finish(nl_handle_t h, void* stream, int sync);
+
 /* Waits for the last enqueued build and returns its status (replaces the harness's
  * checkCudaErrors(cudaDeviceSynchronize()), make_list.cu:128). */
 int nl_synchronize(nl_handle_t h);

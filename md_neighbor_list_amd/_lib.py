@@ -27,6 +27,8 @@ PROTOTYPES = {
     "nl_destroy": (C.c_int, [_P]),
     "nl_make_list": (C.c_int, [_P, _P, _I32, _I32, _P, C.c_int]),
     "nl_make_list_slab": (C.c_int, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _P, C.c_int]),
+    "nl_make_list_slab_begin": (C.c_int, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "nl_make_list_slab_finish": (C.c_int, [_P, _P, C.c_int]),
     "nl_synchronize": (C.c_int, [_P]),
     "nl_get_half_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "nl_get_full_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),

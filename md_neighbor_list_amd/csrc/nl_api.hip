@@ -109,6 +109,8 @@ struct nl_handle_s {
     }
   } graph_key;
   uint64_t buffers_epoch = 1;  // bumped by every (re)allocation
+  bool begun = false;  // nl_make_list_slab_begin has run, nl_make_list_slab_finish has not
+  int32_t begun_ghost_lo = 0, begun_zlo = 0, begun_zhi = 0;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[NL_NUM_STAGES + 1] = {};
 
@@ -325,9 +327,14 @@ template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) 
 }
 
 // Enqueues one whole build. ev != nullptr: records an event before every stage and one after the last.
+// part: PART_ALL = the whole build; PART_BEGIN = everything that needs the OWNED particles only (slab builds: memset +
+// the binning pass over [0, n_rows)); PART_FINISH = the rest (the binning pass over the ghosts, search, scan,
+// expansion).  BEGIN + FINISH = ALL for the caller; between the two the halo exchange may still be writing the ghosts.
+enum { PART_ALL = 0, PART_BEGIN = 1, PART_FINISH = 2 };
 template <typename T>
 int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_t* gid, int32_t n_rows, int32_t n,
-                  int32_t z_lo, int32_t mzl, int32_t slab, hipStream_t s, hipEvent_t* ev) {
+                  int32_t z_lo, int32_t mzl, int32_t slab, hipStream_t s, hipEvent_t* ev, int part = PART_ALL,
+                  int32_t n_ghost_lo = 0) {
   const Grid<T> g = make_grid<T>(h, n_rows, z_lo, mzl, slab);
   const int64_t ncl = (int64_t)h->m[0] * h->m[1] * mzl;
   h->ncell_local = ncl;
@@ -350,24 +357,47 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   const bool two_level = h->bin_two_level && nrows <= BIN_MAX_ROWS && h->m[0] <= BIN_MAX_MX;
   // One allocation = [cell histogram | status, tickets, total (32 words) | row totals]: one memset node clears
   // what this build's path needs (histogram + meta, or meta + row totals).
+  // two binning passes: owned, then ghosts (the persistent sweep, variant 2, has its own cell walk without the guard
+  // against an inconsistent cell table: no split there)
+  const bool split = part != PART_ALL && two_level && slab && h->sweep_variant != 2;
+  if (part != PART_ALL && !split) {  // nothing to overlap on this path: BEGIN does nothing, FINISH is the whole build
+    if (part == PART_BEGIN) return NL_OK;
+    part = PART_ALL;
+  }
   if (two_level) {
-    HIPCHK(h, hipMemsetAsync(h->cell_count + h->ncell, 0, sizeof(int32_t) * (size_t)(32 + nrows), s));
-    if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
-    if (n > 0)
-      hipLaunchKernelGGL((k_bin_rows<T>), dim3(h->bin_blocks), dim3(BIN_THREADS), 0, s, q, stride, n, h->bin_chunk, g, nrows,
-                         h->row_count, h->blk_base, h->status);
-    if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_CELL_SCAN], s));
-    // (no scan launch: every block of k_bin_scatter scans the row totals itself and block 0 publishes row_start)
-    if (n <= 0) {
-      if (int rc = launch_scan(h, h->row_count, nrows, h->row_start, h->totals, s)) return rc;
+    const int32_t my = h->m[1];
+    // the three launches of one pass; rc_arr / rs_arr: the pass's own row totals and row starts
+    auto run_pass = [&](const BinPhase& ph, int32_t* rc_arr, int32_t* rs_arr, int32_t cells_grid, bool events) {
+      const int32_t np = ph.i_end - ph.i_beg;
+      const int32_t blocks = std::max(1, (np + h->bin_chunk - 1) / h->bin_chunk);  // (an empty pass still publishes its row starts)
+      hipLaunchKernelGGL((k_bin_rows<T>), dim3(blocks), dim3(BIN_THREADS), 0, s, q, stride, n, h->bin_chunk, g, nrows, rc_arr,
+                         h->blk_base, h->status, ph);
+      if (events) (void)hipEventRecord(ev[NL_STAGE_CELL_SCAN], s);
+      // (no scan launch: every block of k_bin_scatter scans the row totals itself and block 0 publishes the row starts)
+      if (events) (void)hipEventRecord(ev[NL_STAGE_REORDER], s);
+      hipLaunchKernelGGL((k_bin_scatter<T>), dim3(blocks), dim3(BIN_THREADS), 0, s, q, stride, gid, n, h->bin_chunk, g, nrows,
+                         rc_arr, rs_arr, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row, h->status, ph);
+      hipLaunchKernelGGL((k_bin_cells<T>), dim3(cells_grid), dim3(256), 0, s, g, nrows, rs_arr,
+                         static_cast<const Pos<T>*>(h->tmp_pos), h->tmp_row, h->cell_start, static_cast<Pos<T>*>(h->sorted),
+                         h->sorted_row, h->sorted_gid, ph);
+    };
+    if (!split) {
+      HIPCHK(h, hipMemsetAsync(h->cell_count + h->ncell, 0, sizeof(int32_t) * (size_t)(32 + nrows), s));
+      if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
+      const BinPhase all = {0, n, nrows, 0, 0, 0, nrows, nrows, -1};
+      run_pass(all, h->row_count, h->row_start, nrows, ev != nullptr);
+    } else if (part == PART_BEGIN) {
+      // owned particles: rows of the layers 1 .. mzl-2, placed behind the n_ghost_lo particles of ghost layer 0
+      HIPCHK(h, hipMemsetAsync(h->cell_count + h->ncell, 0, sizeof(int32_t) * (size_t)(32 + 2 * (size_t)nrows), s));
+      const BinPhase owned = {0, n_rows, nrows, n_ghost_lo, n_ghost_lo, my, nrows - 2 * my, nrows, -1};
+      run_pass(owned, h->row_count, h->row_start, nrows - 2 * my, false);
+      HIPCHK(h, hipGetLastError());
+      return NL_OK;
+    } else {
+      // ghosts: layer 0 at the front of the sorted array, layer mzl-1 behind the owned particles
+      const BinPhase ghosts = {n_rows, n, nrows - my, 0, n_rows, 0, my, nrows - my, n_ghost_lo};
+      run_pass(ghosts, h->row_count + nrows, h->row_start + nrows + 16, 2 * my, false);
     }
-    if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_REORDER], s));
-    if (n > 0)
-      hipLaunchKernelGGL((k_bin_scatter<T>), dim3(h->bin_blocks), dim3(BIN_THREADS), 0, s, q, stride, gid, n, h->bin_chunk, g,
-                         nrows, h->row_count, h->row_start, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row);
-    hipLaunchKernelGGL((k_bin_cells<T>), dim3(nrows), dim3(256), 0, s, g, nrows, h->row_start,
-                       static_cast<const Pos<T>*>(h->tmp_pos), h->tmp_row, h->cell_start, static_cast<Pos<T>*>(h->sorted),
-                       h->sorted_row, h->sorted_gid);
   } else {
     HIPCHK(h, hipMemsetAsync(h->cell_count, 0, sizeof(int32_t) * (size_t)(h->ncell + 32), s));
     if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
@@ -397,9 +427,10 @@ int enqueue_result_copy(nl_handle_t h, hipStream_t s) {
 }
 
 int dispatch_build(nl_handle_t h, const void* q, int32_t stride, const int32_t* gid, int32_t n_rows, int32_t n,
-                   int32_t z_lo, int32_t mzl, int32_t slab, hipStream_t s, hipEvent_t* ev) {
-  return h->dtype == NL_F32 ? enqueue_build<float>(h, q, stride, gid, n_rows, n, z_lo, mzl, slab, s, ev)
-                            : enqueue_build<double>(h, q, stride, gid, n_rows, n, z_lo, mzl, slab, s, ev);
+                   int32_t z_lo, int32_t mzl, int32_t slab, hipStream_t s, hipEvent_t* ev, int part = PART_ALL,
+                   int32_t n_ghost_lo = 0) {
+  return h->dtype == NL_F32 ? enqueue_build<float>(h, q, stride, gid, n_rows, n, z_lo, mzl, slab, s, ev, part, n_ghost_lo)
+                            : enqueue_build<double>(h, q, stride, gid, n_rows, n, z_lo, mzl, slab, s, ev, part, n_ghost_lo);
 }
 
 // Default list capacity (unless the caller fixed it): ideal-gas estimate of the half-pair count
@@ -606,7 +637,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
     while ((n + h->bin_chunk - 1) / h->bin_chunk > 1024) h->bin_chunk *= 2;
     h->bin_blocks = (int32_t)((n + h->bin_chunk - 1) / h->bin_chunk);
     if (h->bin_blocks < 1) h->bin_blocks = 1;
-    if ((rc = dev_alloc(h, &h->row_start, 4 * (nrows + 32)))) return rc;
+    if ((rc = dev_alloc(h, &h->row_start, 4 * (2 * nrows + 64)))) return rc;  // (two arrays: a split slab build has two passes)
     if ((rc = dev_alloc(h, &h->blk_base, 4 * (nrows * (size_t)h->bin_blocks + 16)))) return rc;
     if ((rc = dev_alloc(h, &h->tmp_pos, pos_bytes * (n + 16)))) return rc;
     if ((rc = dev_alloc(h, &h->tmp_row, 4 * (n + 16)))) return rc;
@@ -614,7 +645,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   if (h->sweep_variant >= 3 && (rc = dev_alloc(h, &h->masks, (size_t)MASK_ROW_BYTES * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->dbg_buf, 8 * (64 + 4 * 4096)))) return rc;
   HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
-  if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64 + (size_t)h->m[1] * h->m[2])))) return rc;
+  if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64 + 2 * (size_t)h->m[1] * h->m[2])))) return rc;
   h->row_count = h->cell_count + h->ncell + 32;
   if ((rc = dev_alloc(h, &h->cell_start, 4 * ((size_t)h->ncell + 32)))) return rc;
   const size_t nblk = std::max<size_t>(n, (size_t)h->ncell) / SCAN_BLOCK + 2;
@@ -622,7 +653,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   if ((rc = dev_alloc(h, &h->totals, 8 * 4))) return rc;
   h->status = reinterpret_cast<uint32_t*>(h->cell_count + h->ncell);  // cleared by the same memset as the histogram
   HIPCHK(h, hipMemset(h->totals, 0, 32));
-  HIPCHK(h, hipMemset(h->cell_count, 0, 4 * ((size_t)h->ncell + 64 + (size_t)h->m[1] * h->m[2])));
+  HIPCHK(h, hipMemset(h->cell_count, 0, 4 * ((size_t)h->ncell + 64 + 2 * (size_t)h->m[1] * h->m[2])));
   h->n_max = n_max;
   if ((rc = estimate_capacity(h))) return rc;
   h->t_valid = false;
@@ -677,12 +708,22 @@ int nl_set_capacity(nl_handle_t h, int64_t max_pairs) {
   return NL_OK;
 }
 
-int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
-                      int32_t n, int32_t z_lo, int32_t z_hi, void* stream, int sync) {
+namespace {
+// part = PART_ALL: the whole build.  PART_BEGIN: validate, remember the arguments, enqueue what needs only the owned
+// particles.  PART_FINISH: enqueue the rest with the remembered arguments.
+int make_list_slab_part(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
+                        int32_t n, int32_t n_ghost_lo, int32_t z_lo, int32_t z_hi, void* stream, int sync, int part) {
   if (!h) return NL_ERR_ARG;
+  if (part == PART_FINISH) {
+    if (!h->begun) return fail(h, NL_ERR_STATE);
+    q_dev = h->b_q, q_stride = h->b_stride, gid_dev = h->b_gid, n_rows = h->n_rows, n = h->n, n_ghost_lo = h->begun_ghost_lo;
+    z_lo = h->begun_zlo, z_hi = h->begun_zhi;
+  }
+  h->begun = false;
   if (h->n_max <= 0 && n > 0) return fail(h, NL_ERR_STATE);
   if (n < 0 || n_rows < 0 || n_rows > n || n > h->n_max || (q_stride != 3 && q_stride != 4) || (!q_dev && n > 0))
     return fail(h, NL_ERR_ARG);
+  if (n_ghost_lo < 0 || n_ghost_lo > n - n_rows) return fail(h, NL_ERR_ARG);
   if (gid_dev == NL_GID_IN_W && q_stride != 4) return fail(h, NL_ERR_ARG);
   const int32_t mz = h->m[2];
   if (z_lo < 0 || z_hi > mz || z_lo >= z_hi) return fail(h, NL_ERR_ARG);
@@ -709,7 +750,14 @@ int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const 
   h->t_valid = false;
   h->n = n, h->n_rows = n_rows;
   int rc;
-  if (h->use_graph) {
+  if (part == PART_BEGIN) {
+    rc = dispatch_build(h, q_dev, q_stride, gid_dev, n_rows, n, z_lo, mzl, slab, s, nullptr, PART_BEGIN, n_ghost_lo);
+    if (rc) return rc;
+    h->begun = true, h->begun_ghost_lo = n_ghost_lo, h->begun_zlo = z_lo, h->begun_zhi = z_hi;
+    h->last_stream = s;
+    return NL_OK;
+  }
+  if (h->use_graph && part == PART_ALL) {
     nl_handle_s::GraphKey key;
     key.q = q_dev, key.gid = gid_dev, key.stride = q_stride, key.n_rows = n_rows, key.n = n, key.z_lo = z_lo, key.mzl = mzl;
     key.slab = slab, key.list_kind = h->list_kind, key.pbc = h->pbc ? 1 : 0, key.capacity = h->capacity;
@@ -734,7 +782,7 @@ int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const 
     }
     HIPCHK(h, hipGraphLaunch(h->graph_exec, s));
   } else {
-    rc = dispatch_build(h, q_dev, q_stride, gid_dev, n_rows, n, z_lo, mzl, slab, s, nullptr);
+    rc = dispatch_build(h, q_dev, q_stride, gid_dev, n_rows, n, z_lo, mzl, slab, s, nullptr, part, n_ghost_lo);
     if (rc) return rc;
     rc = enqueue_result_copy(h, s);
     if (rc) return rc;
@@ -743,6 +791,21 @@ int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const 
   h->pending = true;
   if (sync) return finish(h, true);
   return NL_OK;
+}
+}  // namespace
+
+int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
+                      int32_t n, int32_t z_lo, int32_t z_hi, void* stream, int sync) {
+  return make_list_slab_part(h, q_dev, q_stride, gid_dev, n_rows, n, 0, z_lo, z_hi, stream, sync, PART_ALL);
+}
+
+int nl_make_list_slab_begin(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
+                            int32_t n, int32_t n_ghost_lo, int32_t z_lo, int32_t z_hi, void* stream) {
+  return make_list_slab_part(h, q_dev, q_stride, gid_dev, n_rows, n, n_ghost_lo, z_lo, z_hi, stream, 0, PART_BEGIN);
+}
+
+int nl_make_list_slab_finish(nl_handle_t h, void* stream, int sync) {
+  return make_list_slab_part(h, nullptr, 0, nullptr, 0, 0, 0, 0, 0, stream, sync, PART_FINISH);
 }
 
 int nl_make_list(nl_handle_t h, const void* q_dev, int32_t q_stride, int32_t n, void* stream, int sync) {

@@ -382,15 +382,29 @@ constexpr int BIN_UNROLL = 4;  // particles per thread whose loads are in flight
 constexpr int BIN_MAX_ROWS = 12288;  // 48 KiB of LDS counters
 constexpr int BIN_MAX_MX = 4096;
 
+// One pass of the binning kernels over a range of particles.  A whole build is one pass over [0, n).  A slab build that
+// overlaps the halo exchange (nl_make_list_slab_begin / _finish) runs two: the owned particles [0, n_rows) first --
+// their rows of x-cells are the layers 1 .. mzl-2, which start right behind the n_ghost_lo particles of ghost layer 0
+// in the sorted array -- and the ghosts [n_rows, n) when they have arrived: layer 0 at the front, layer mzl-1 behind
+// the owned particles.  The three regions of the sorted array never overlap, so the passes are independent.
+struct BinPhase {
+  int32_t i_beg, i_end;        // particles of this pass
+  int32_t split_row;           // a row r starts at (r < split_row ? base_lo : base_hi) + (this pass's particles in rows < r)
+  int32_t base_lo, base_hi;
+  int32_t cells_row0, cells_n0, cells_row1;  // k_bin_cells: block b < cells_n0 -> row cells_row0 + b, else cells_row1 + b - cells_n0
+  int32_t check_lo;            // >= 0: this pass must hold exactly that many particles in rows < split_row (ST_DOMAIN)
+};
+
 template <typename T>
 __global__ void __launch_bounds__(BIN_THREADS) k_bin_rows(const T* __restrict__ q, int32_t stride, int32_t n, int32_t chunk,
                                                           Grid<T> g, int32_t nrows, int32_t* __restrict__ row_count,
-                                                          int32_t* __restrict__ blk_base, uint32_t* __restrict__ status) {
+                                                          int32_t* __restrict__ blk_base, uint32_t* __restrict__ status,
+                                                          BinPhase ph) {
   __shared__ int32_t hist[BIN_MAX_ROWS];
   const int tid = threadIdx.x;
   for (int32_t r = tid; r < nrows; r += BIN_THREADS) hist[r] = 0;
   __syncthreads();
-  const int32_t beg = blockIdx.x * chunk, end = min(beg + chunk, n);
+  const int32_t beg = ph.i_beg + blockIdx.x * chunk, end = min(beg + chunk, ph.i_end);
   // BIN_UNROLL particles per thread and trip, all loads first: one memory round trip per trip instead of one per
   // particle (a chunk is 4 particles per thread).
   for (int32_t i0 = beg + tid; i0 < end; i0 += BIN_UNROLL * BIN_THREADS) {
@@ -427,7 +441,8 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
                                                              Grid<T> g, int32_t nrows, const int32_t* __restrict__ row_count,
                                                              int32_t* __restrict__ row_start,
                                                              const int32_t* __restrict__ blk_base, Pos<T>* __restrict__ tmp,
-                                                             int32_t* __restrict__ tmp_row) {
+                                                             int32_t* __restrict__ tmp_row, uint32_t* __restrict__ status,
+                                                             BinPhase ph) {
   __shared__ int32_t cursor[BIN_MAX_ROWS];
   __shared__ int32_t wsum[BIN_THREADS / WAVE];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -451,14 +466,18 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
     }
     int32_t run = woff + inc - ssum;
     for (int32_t i = b; i < e; i++) {
-      cursor[i] = run + blk_base[(size_t)blockIdx.x * nrows + i];
-      if (blockIdx.x == 0) row_start[i] = run;
+      const int32_t start = run + (i < ph.split_row ? ph.base_lo : ph.base_hi);
+      cursor[i] = start + blk_base[(size_t)blockIdx.x * nrows + i];
+      if (blockIdx.x == 0) {
+        row_start[i] = start;
+        if (i == ph.split_row && ph.check_lo >= 0 && run != ph.check_lo) atomicOr(status, ST_DOMAIN);
+      }
       run += row_count[i];
     }
-    if (blockIdx.x == 0 && tid == 0) row_start[nrows] = all;
+    if (blockIdx.x == 0 && tid == 0) row_start[nrows] = all + ph.base_hi;
   }
   __syncthreads();
-  const int32_t beg = blockIdx.x * chunk, end = min(beg + chunk, n);
+  const int32_t beg = ph.i_beg + blockIdx.x * chunk, end = min(beg + chunk, ph.i_end);
   const bool gid_in_w = gid == reinterpret_cast<const int32_t*>(1);  // NL_GID_IN_W: the id travels in the w component
   for (int32_t i0 = beg + tid; i0 < end; i0 += BIN_UNROLL * BIN_THREADS) {  // all loads of a trip first (see k_bin_rows)
     T x[BIN_UNROLL], y[BIN_UNROLL], z[BIN_UNROLL];
@@ -499,12 +518,14 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, const int32_t* __restrict__ row_start,
                                                    const Pos<T>* __restrict__ tmp, const int32_t* __restrict__ tmp_row,
                                                    int32_t* __restrict__ cell_start, Pos<T>* __restrict__ sorted,
-                                                   int32_t* __restrict__ sorted_row, int32_t* __restrict__ sorted_gid) {
+                                                   int32_t* __restrict__ sorted_row, int32_t* __restrict__ sorted_gid,
+                                                   BinPhase ph) {
   __shared__ int32_t cnt[BIN_MAX_MX];
   __shared__ int32_t wsum[4];
   __shared__ int32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int32_t r = blockIdx.x, mx = g.m[0];
+  const int32_t bx = blockIdx.x, mx = g.m[0];
+  const int32_t r = bx < ph.cells_n0 ? ph.cells_row0 + bx : ph.cells_row1 + (bx - ph.cells_n0);
   const int32_t beg = row_start[r], end = row_start[r + 1];
   for (int32_t c = tid; c < mx; c += 256) cnt[c] = 0;
   if (tid == 0) carry_s = 0;
@@ -760,6 +781,10 @@ template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs
   const int32_t wy = (int32_t)fastdiv((uint32_t)w, a.div_mx), cx = w - wy * a.mx;
   const int32_t wz = (int32_t)fastdiv((uint32_t)wy, a.div_my), cy = wy - wz * a.my, cz = wz + (a.slab ? 1 : 0);
   const int32_t cell = cx + (cy + cz * a.my) * a.mx;
+  // A build whose binning has flagged the particles as inconsistent with the slab description (ST_DOMAIN: a particle
+  // in the wrong layer, or -- split slab builds -- a ghost count that does not match the data) may have overlapping
+  // regions in the sorted array and a cell table that is not monotonic: nobody walks it.  (Read with the cell table.)
+  const uint32_t st_word = *a.status;
   c.ibeg = a.cell_start[cell];
   c.ni = a.cell_start[cell + 1] - c.ibeg;
   c.cx = cx, c.cy = cy, c.cz = cz;
@@ -794,7 +819,7 @@ template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs
     const int32_t wz = a.slab ? 0 : cz + dz < 0 ? -1 : cz + dz >= a.mzl ? 1 : 0;
     c.wrap = (wx + 1) | (wy + 1) << 2 | (wz + 1) << 4;
   }
-  if (c.ni == 0) return false;
+  if (c.ni <= 0 || (st_word & ST_DOMAIN)) return false;
   c.seg_off = scan32_dpp(c.seg_len) - c.seg_len;  // exclusive offsets in the staged stream
   c.total_j = __builtin_amdgcn_readlane(c.seg_off + c.seg_len, NSEG - 1);
   return true;

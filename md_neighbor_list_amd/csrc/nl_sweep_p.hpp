@@ -326,7 +326,9 @@ __global__ void __launch_bounds__(256) k_row_base(const int32_t* __restrict__ ke
   const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const int32_t r = sorted_row[s];
-  base_sorted[s] = r < n_rows ? key_pointer[r] : 0;  // ghosts (slab builds) have no row
+  // ghosts (slab builds) have no row; in a build that failed its checks a slot may never have been written: unsigned
+  // compare, so that whatever it holds is not used as an index
+  base_sorted[s] = (uint32_t)r < (uint32_t)n_rows ? key_pointer[r] : 0;
 }
 
 }  // namespace nl

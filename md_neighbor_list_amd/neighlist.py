@@ -157,6 +157,33 @@ class NeighListGPU:
             "nl_make_list_slab",
         )
 
+    def MakeNeighListSlabBegin(self, q, gid, n_rows, n_ghost_lo, z_lo, z_hi):
+        """nl_make_list_slab_begin: the part of a slab build that needs only the owned particles q[:n_rows]; the ghost
+        rows of q may still be in flight.  Follow with MakeNeighListSlabFinish once the current stream waits for them."""
+        n = self._check_q(q, None)
+        if isinstance(gid, str):
+            if gid != self.GID_IN_W or q.shape[1] != 4:
+                raise TypeError("gid='w' needs 4-component positions")
+            gid_ptr = 1
+        elif gid is not None:
+            if gid.device.type != "cuda" or gid.dtype != torch.int32 or gid.numel() != n or not gid.is_contiguous():
+                raise TypeError("gid must be a contiguous int32 device tensor with one id per particle")
+            gid_ptr = gid.data_ptr()
+        else:
+            gid_ptr = None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._q = (q, gid)
+        self._n, self._n_rows = n, int(n_rows)
+        check(
+            self._lib.nl_make_list_slab_begin(self._h, q.data_ptr(), q.shape[1], gid_ptr, int(n_rows), n, int(n_ghost_lo),
+                                              int(z_lo), int(z_hi), stream),
+            "nl_make_list_slab_begin",
+        )
+
+    def MakeNeighListSlabFinish(self, sync=True):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        check(self._lib.nl_make_list_slab_finish(self._h, stream, 1 if sync else 0), "nl_make_list_slab_finish")
+
     def synchronize(self):
         check(self._lib.nl_synchronize(self._h), "nl_synchronize")
 

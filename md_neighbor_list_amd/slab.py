@@ -78,12 +78,13 @@ class SlabState:
         return self.n_rows + self.n_ghost_lo + self.n_ghost_hi
 
 
-def _p2p(ops_spec, staging_cpu: bool):
-    """ops_spec: list of ("send"|"recv", tensor, peer).  One grouped batch of point-to-point transfers."""
+def _p2p(ops_spec, staging_cpu: bool, defer: bool = False):
+    """ops_spec: list of ("send"|"recv", tensor, peer).  One grouped batch of point-to-point transfers.
+    defer: start the transfers and return the function that completes them (None when there is nothing to wait for)."""
     # An empty boundary layer sends nothing: both sides know the count (setup exchanged it), so both skip the message.
     ops_spec = [(kind, t, peer) for kind, t, peer in ops_spec if t.numel() > 0]
     if not ops_spec:
-        return
+        return None
     bufs, ops = [], []
     for kind, t, peer in ops_spec:
         if staging_cpu:
@@ -92,11 +93,19 @@ def _p2p(ops_spec, staging_cpu: bool):
             ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, c, peer))
         else:
             ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    for kind, t, c in bufs:
-        if kind == "recv":
-            t.copy_(c)
+    works = dist.batch_isend_irecv(ops)
+
+    def complete():
+        for w in works:
+            w.wait()  # (RCCL: makes the current stream wait; gloo: blocks the host)
+        for kind, t, c in bufs:
+            if kind == "recv":
+                t.copy_(c)
+
+    if not defer:
+        complete()
+        return None
+    return complete
 
 
 def _staging():
@@ -147,12 +156,12 @@ def setup(q_global: torch.Tensor, gid_global: torch.Tensor | None, box, rc, rank
     return SlabState(rank, world, z_lo, z_hi, n_rows, q_all, gid_all, send_lo, send_hi, n_glo, n_ghi)
 
 
-def exchange_ghosts(st: SlabState) -> None:
+def exchange_ghosts(st: SlabState, defer: bool = False):
     """The per-build halo exchange: my bottom layer goes down, my top layer goes up; the neighbours' layers land
     directly in the ghost region of q_all / gid_all.  With world == 2 both neighbours are the same rank: the send
     of my bottom layer pairs with its receive of 'upper ghosts' by message order inside the batch."""
     if st.world == 1:
-        return
+        return None
     lo_peer, hi_peer = (st.rank - 1) % st.world, (st.rank + 1) % st.world
     n0, n1 = st.n_rows, st.n_rows + st.n_ghost_lo
     in_w = st.q_all.shape[1] == 4  # ids travel inside the positions
@@ -174,14 +183,24 @@ def exchange_ghosts(st: SlabState) -> None:
     # Order matters when lo_peer == hi_peer (world 2): the peer posts [its bottom layer, its top layer]; its bottom
     # layer is MY upper ghost layer and its top layer my lower one, so the upper-ghost receive is posted first.
     recvs = recv_hi + recv_lo if lo_peer == hi_peer else recv_lo + recv_hi
-    _p2p(sends + recvs, _staging())
+    return _p2p(sends + recvs, _staging(), defer)
 
 
-def build(nl, st: SlabState, sync=True) -> None:
+def build(nl, st: SlabState, sync=True, overlap=True) -> None:
     """One domain-decomposed build on this rank: halo exchange, then the slab build on owned + ghost particles."""
-    exchange_ghosts(st)
     gid = nl.GID_IN_W if st.q_all.shape[1] == 4 else st.gid_all
     if st.world == 1:
         nl.MakeNeighListSlab(st.q_all, gid, st.n_rows, 0, nl.mesh_size[2], sync=sync)
-    else:
+        return
+    if not overlap:
+        exchange_ghosts(st)
         nl.MakeNeighListSlab(st.q_all, gid, st.n_rows, st.z_lo, st.z_hi, sync=sync)
+        return
+    # The exchange is started, the binning of the OWNED layers is enqueued behind the pack kernel on the current stream
+    # (it reads q_all[:n_rows] only and fills the owned region of the cell-sorted array), then the current stream is
+    # made to wait for the ghosts and the rest of the build follows: the transfer runs under the owned binning.
+    complete = exchange_ghosts(st, defer=True)
+    nl.MakeNeighListSlabBegin(st.q_all, gid, st.n_rows, st.n_ghost_lo, st.z_lo, st.z_hi)
+    if complete is not None:
+        complete()
+    nl.MakeNeighListSlabFinish(sync=sync)

@@ -64,3 +64,49 @@ def test_slab_union_equals_global_list_gpu(world, case):
 def test_slab_union_equals_global_minimum_image_list_gpu(world, case):
     res = run(world, "hip_pbc", case)
     assert res[0] == "ok"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,pbc", [("float32", False), ("float64", False), ("float32", True)])
+def test_split_slab_build_equals_the_single_call(dtype, pbc):
+    """nl_make_list_slab_begin + _finish (owned layers binned first, ghosts later: what slab.build does so that the
+    halo exchange overlaps the first part) against nl_make_list_slab on the same slab of a box, one process: identical
+    rows; a wrong n_ghost_lo is reported, not used."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU, inputs
+    from md_neighbor_list_amd._lib import NLError
+    from tests.util import canonical_csr
+
+    dt = np.float32 if dtype == "float32" else np.float64
+    rc, box = 3.3, (27.0, 24.0, 40.0)  # 12 layers
+    q, box = inputs.uniform_box(42000, dtype=dt, seed=77, box=box)
+    mz = int(box[2] / rc)
+    iz = slab.z_layer(torch.from_numpy(q), box, rc).numpy()
+    for z_lo, z_hi in ((4, 8), (0, 5), (9, 12)):
+        own = np.nonzero((iz >= z_lo) & (iz < z_hi))[0]
+        glo = np.nonzero(iz == (z_lo - 1) % mz)[0]
+        ghi = np.nonzero(iz == z_hi % mz)[0]
+        order = np.concatenate([own, glo, ghi])
+        qa = torch.from_numpy(q[order]).cuda()
+        gid = torch.from_numpy(order.astype(np.int32)).cuda()
+        tdt = torch.float32 if dt == np.float32 else torch.float64
+        res = []
+        for split in (False, True):
+            nl = NeighListGPU(rc, *box, dtype=tdt, minimum_image=pbc)
+            nl.Initialize(len(order))
+            if split:
+                nl.MakeNeighListSlabBegin(qa, gid, len(own), len(glo), z_lo, z_hi)
+                nl.MakeNeighListSlabFinish(sync=True)
+            else:
+                nl.MakeNeighListSlab(qa, gid, len(own), z_lo, z_hi, sync=True)
+            kp, sl = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
+            res.append((kp, canonical_csr(kp, sl)))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        assert int(res[0][0][-1]) > 0
+        if len(glo) > 3:
+            nl = NeighListGPU(rc, *box, dtype=tdt, minimum_image=pbc)
+            nl.Initialize(len(order))
+            nl.MakeNeighListSlabBegin(qa, gid, len(own), len(glo) - 3, z_lo, z_hi)
+            with pytest.raises(NLError):
+                nl.MakeNeighListSlabFinish(sync=True)
