@@ -94,8 +94,10 @@ def _p2p(ops_spec, staging_cpu: bool, defer: bool = False):
         else:
             ops.append(dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer))
     works = dist.batch_isend_irecv(ops)
+    keep_alive = (ops, ops_spec)  # the send buffers must outlive the transfers when completion is deferred
 
     def complete():
+        _ = keep_alive
         for w in works:
             w.wait()  # (RCCL: makes the current stream wait; gloo: blocks the host)
         for kind, t, c in bufs:
