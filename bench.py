@@ -120,7 +120,7 @@ def _traffic_from_profiles(kernel):
         return None
 
 
-def _reference_pairs(n_total, density, dtype, got):
+def _reference_pairs(n_total, density, dtype, got, world=1, weak=True):
     """The pair count of this box from the compiled reference (tests/golden/known_answers.json, written by
     oracle/gen_golden.py --big; a committed fixture, nothing under oracle/ runs here): "ok" when the build (the union
     over ranks for N > 1) found exactly that many pairs, the two numbers otherwise, None when no answer is stored."""
@@ -130,7 +130,8 @@ def _reference_pairs(n_total, density, dtype, got):
         return None
     if n_total % (1 << 20):
         return None
-    key = f"u{n_total >> 20}M_rho{'1' if density == 1.0 else '05'}_{dtype}"
+    rho = "1" if density == 1.0 else "05"
+    key = f"u1M_rho{rho}_{dtype}" if world == 1 else f"w{world}x1M_rho{rho}_{dtype}" if weak else f"u{n_total >> 20}M_rho{rho}_{dtype}"
     if key not in ka:
         return None
     want = int(ka[key]["npairs"])
@@ -182,7 +183,12 @@ def main():
     else:
         n_total, scaling = N_PER_GPU * world, "weak"
     np_dtype, t_dtype = (np.float32, torch.float32) if args.dtype == "f32" else (np.float64, torch.float64)
-    q, box = inputs.uniform_box(n_total, density, np_dtype)  # every rank generates the same box
+    if args.workload == "cfg4":
+        q, box = inputs.uniform_box(n_total, density, np_dtype)  # the cubic 33.5 M box; every rank generates the same
+    else:
+        # weak scaling: the single-GPU cube repeated `world` times along z, so that every rank's slab is the N = 1
+        # problem plus its two ghost layers (world = 1: the cube itself, BASELINE config 2 / 3)
+        q, box = inputs.weak_scaling_box(world, N_PER_GPU, density, np_dtype)
     mesh = slab.mesh_of(box, RC)
 
     nl = NeighListGPU(RC, *box, dtype=t_dtype, device=dev)
@@ -275,11 +281,11 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             **({"rehearsal": "ranks share one GPU over gloo: not a measurement"} if rehearsal else {}),
-            "config": {"workload": f"uniform random box, N={n_total}, rho={density}, rc={RC}, "
+            "config": {"workload": f"uniform random box {box[0]:.2f} x {box[1]:.2f} x {box[2]:.2f}, N={n_total}, rho={density}, rc={RC}, "
                                    f"{'fp32 float4' if args.dtype == 'f32' else 'fp64 double4'} positions, half list "
                                    f"(CSR in original particle order), mesh {mesh[0]}x{mesh[1]}x{mesh[2]}",
                        "n_particles": n_total, "half_pairs": npairs,
-                       "half_pairs_reference": _reference_pairs(n_total, density, args.dtype, npairs),
+                       "half_pairs_reference": _reference_pairs(n_total, density, args.dtype, npairs, world, scaling == "weak"),
                        "decomposition": "none" if world == 1 else f"{world} z-slabs + 1-cell ghost layers (p2p)"},
             "build": {"algorithmic_bytes": b_build, "achieved_GBs": round(build_gbs, 1),
                       "frac_of_hbm_peak": round(build_gbs / HBM_PEAK_GBS, 4)},

@@ -68,6 +68,14 @@ def uniform_box(n: int, density: float = 1.0, dtype=np.float32, seed: int = 1234
     return q, tuple(float(b) for b in box)
 
 
+def weak_scaling_box(n_ranks: int, n_per_rank: int = 1 << 20, density: float = 1.0, dtype=np.float32, seed: int = 12345):
+    """The box of a weak-scaling run over ``n_ranks`` z-slabs: the single-GPU cube (side cbrt(n_per_rank / rho))
+    repeated ``n_ranks`` times along z, filled with n_ranks * n_per_rank uniform random particles -- every rank's slab
+    is the single-GPU problem plus its two ghost layers, whatever the number of ranks.  n_ranks = 1 is uniform_box."""
+    L = box_length(n_per_rank, density)
+    return uniform_box(n_ranks * n_per_rank, density, dtype, seed, box=(L, L, n_ranks * L))
+
+
 def fcc_box(density: float = 1.0, L: float = 50.0, dtype=np.float64):
     """Returns ``(q, (L, L, L))``; N = 4 * int(L / s)**3 (119 164 at rho=1, 62 500 at rho=0.5)."""
     lib = _load()

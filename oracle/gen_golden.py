@@ -105,10 +105,14 @@ def big(only=None):
         ("u1M_rho1_f64", lambda: inputs.uniform_box(1 << 20, 1.0, np.float64), 3.3),
         ("u1M_rho05_f32", lambda: inputs.uniform_box(1 << 20, 0.5, np.float32), 3.3),  # BASELINE config 3
         ("u1M_rho05_f64", lambda: inputs.uniform_box(1 << 20, 0.5, np.float64), 3.3),
-        # the weak-scaling boxes of bench.py --gpus 2 / 4 / 8 (N x 1 048 576 particles at rho = 1)
+        # cubic boxes of 2 / 4 / 8 M particles at rho = 1
         ("u2M_rho1_f32", lambda: inputs.uniform_box(2 << 20, 1.0, np.float32), 3.3),
         ("u4M_rho1_f32", lambda: inputs.uniform_box(4 << 20, 1.0, np.float32), 3.3),
         ("u8M_rho1_f32", lambda: inputs.uniform_box(8 << 20, 1.0, np.float32), 3.3),
+        # the weak-scaling boxes of bench.py --gpus 2 / 4 / 8: the 1 M cube repeated along z (inputs.weak_scaling_box)
+        ("w2x1M_rho1_f32", lambda: inputs.weak_scaling_box(2), 3.3),
+        ("w4x1M_rho1_f32", lambda: inputs.weak_scaling_box(4), 3.3),
+        ("w8x1M_rho1_f32", lambda: inputs.weak_scaling_box(8), 3.3),
         ("fcc_L50_rho1_f64", lambda: inputs.fcc_box(1.0, 50.0, np.float64), 3.3),       # the README point
         ("fcc_L50_rho05_f64", lambda: inputs.fcc_box(0.5, 50.0, np.float64), 3.3),
         ("fcc_L50_rho1_f32", lambda: inputs.fcc_box(1.0, 50.0, np.float32), 3.3),

@@ -680,17 +680,22 @@ def test_graph_replay_builds_the_same_lists():
     check(q3, t3, m)
 
 
-@pytest.mark.parametrize("key", ["u2M_rho1_f32", "u8M_rho1_f32"])
+@pytest.mark.parametrize("key", ["w2x1M_rho1_f32", "w8x1M_rho1_f32", "u8M_rho1_f32"])
 def test_weak_scaling_boxes_on_one_gpu(key):
-    """The boxes of bench.py --gpus 2 / 8 (N x 1 048 576 particles) built on ONE GPU against the compiled reference's
-    answers for them: pair count, the checksum and the maximum of number_of_partners -- the numbers the multi-GPU
-    bench line is compared with (`half_pairs_reference`).  No list download (2.5 GB at 8 M)."""
+    """The boxes of bench.py --gpus 2 / 8 (the 1 M cube repeated along z: inputs.weak_scaling_box) and the cubic 8 M
+    box, built on ONE GPU against the compiled reference's answers for them: pair count, the checksum and the maximum
+    of number_of_partners -- the numbers the multi-GPU bench line is compared with (`half_pairs_reference`).  No list
+    download (2.5 GB at 8 M)."""
     import torch
 
     from md_neighbor_list_amd import NeighListGPU
 
     ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))[key]
-    q, box = inputs.uniform_box(ka["n"], 1.0, np.float32)
+    if key.startswith("w"):
+        q, box = inputs.weak_scaling_box(int(key[1:key.index("x")]))
+    else:
+        q, box = inputs.uniform_box(ka["n"], 1.0, np.float32)
+    assert len(q) == ka["n"] and np.allclose(box, ka["box"])
     nl = NeighListGPU(ka["rc"], *box, dtype=torch.float32)
     nl.Initialize(len(q))
     nl.MakeNeighList(torch.from_numpy(q).cuda(), len(q))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What one rank of the 8-GPU weak-scaling run computes, on one GPU and without any exchange: the slab of rank 3 of the
-8 M-particle box (owned layers + two ghost layers), built as slab.build does (begin + finish) and in one call, against
+8 M-particle weak-scaling box (SLAB_COST_BOX=cube: the cubic 8 M box) (owned layers + two ghost layers), built as slab.build does (begin + finish) and in one call, against
 the plain 1 M-particle build."""
 import os, sys, time
 import numpy as np, torch
@@ -21,7 +21,7 @@ qd1 = torch.from_numpy(q1).cuda()
 print(f"plain build, N = 1 M: {timed(lambda: nl1.MakeNeighList(qd1, len(q1), sync=False), nl1.synchronize):.1f} us", flush=True)
 
 world, rank = 8, 3
-q, box = inputs.uniform_box(8 << 20, 1.0, np.float32)
+q, box = inputs.weak_scaling_box(8) if os.environ.get("SLAB_COST_BOX", "weak") == "weak" else inputs.uniform_box(8 << 20, 1.0, np.float32)
 mz = int(box[2] / RC)
 z_lo, z_hi = slab.split_layers(mz, world)[rank]
 iz = slab.z_layer(torch.from_numpy(q), box, RC).numpy()
