@@ -50,7 +50,9 @@ typedef enum nl_status {
   NL_ERR_STATE = 6,          /* call order violated (e.g. make_list before initialize, getter before a build)  */
   NL_ERR_MESH = 7,           /* fewer than 3 cells along an axis: the reference visits cell pairs twice there
                                 and emits duplicate pairs; this library refuses such boxes                     */
-  NL_ERR_INDEX_OVERFLOW = 8, /* more than INT32_MAX pairs on one device with 32-bit key_pointer                */
+  NL_ERR_INDEX_OVERFLOW = 8, /* the list has more than INT32_MAX entries and a 32-bit key_pointer was asked for:
+                                nl_get_*_csr / the transposed list after a wide build, or a build with
+                                nl_set_offset_width(32); the reference wraps silently there (neighlist_cpu.hpp:15,29) */
   NL_ERR_NO_DEVICE = 9,      /* no usable gfx950 device / wrong code object                                    */
   NL_ERR_DOMAIN = 10         /* slab builds: a row particle outside the owned cells or a ghost inside them     */
 } nl_status;
@@ -82,6 +84,16 @@ int nl_set_capacity(nl_handle_t h, int64_t max_pairs);
  * (a full list has twice as many) and is re-estimated unless it was set by nl_set_capacity. */
 enum nl_list_kind { NL_LIST_HALF = 0, NL_LIST_FULL = 1 };
 int nl_set_list_kind(nl_handle_t h, int kind);
+
+/* Width of the list offsets (key_pointer).  The reference's key_pointer_ and number_of_pairs_ are int32
+ * (neighlist_cpu.hpp:15,29; neighlist_gpu.hpp:484-487) and wrap beyond INT32_MAX pairs; BASELINE config 4 has 2.5e9.
+ * 0 (default): a build uses 64-bit offsets as soon as the list capacity of the handle exceeds INT32_MAX entries -- which
+ * the default capacity estimate does for such boxes, and which a synchronous build that overflows reaches by growing
+ * the list -- and 32-bit offsets otherwise; 32 / 64 force one width (a 32-bit build of a longer list fails with
+ * NL_ERR_INDEX_OVERFLOW).  Whatever the build used, nl_get_*_csr returns int32 offsets (converted once per build if
+ * needed, NL_ERR_INDEX_OVERFLOW if they cannot hold the list) and nl_get_*_csr64 int64 offsets.  NL_OFFSET_WIDTH in
+ * the environment sets the default. */
+int nl_set_offset_width(nl_handle_t h, int bits);
 
 /* Launch mode of asynchronous builds ("capture launch-bound inner loops in hipGraphs").  on != 0:
  * a build is captured once into a hipGraph (memset, the kernels, the 80-byte result copy) and replayed on the caller's
@@ -159,6 +171,19 @@ int nl_get_half_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_
 int nl_get_full_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_t** list_dev,
                     const int32_t** number_of_partners_dev, int64_t* nentries);
 
+/* The same lists with 64-bit offsets: key_pointer[N+1] as int64 (no reference counterpart: its offsets are int32,
+ * neighlist_cpu.hpp:29, and BASELINE config 4's 2.5e9 pairs do not fit them). */
+int nl_get_half_csr64(nl_handle_t h, const int64_t** key_pointer_dev, const int32_t** sorted_list_dev,
+                      const int32_t** number_of_partners_dev, int64_t* npairs);
+int nl_get_full_csr64(nl_handle_t h, const int64_t** key_pointer_dev, const int32_t** list_dev,
+                      const int32_t** number_of_partners_dev, int64_t* nentries);
+
+/* Order-independent checksum of the list of the last build, computed on the device: the wrapping sum over entries
+ * (row i, partner j) of mix((id_i << 32) | j), mix(v): v *= 0x9E3779B97F4A7C15; v ^= v >> 29 -- the pair-set hash of
+ * the reference harness's known answers -- with id_i the row's global id (slab builds: the ids the
+ * build was given).  The sum over the ranks of a decomposed build is the checksum of the global list.  Synchronises. */
+int nl_list_checksum(nl_handle_t h, uint64_t* checksum, int64_t* nentries);
+
 /* The GPU class's accessors neigh_list() / number_of_partners() (neighlist_gpu.hpp:468-482): the FULL list in
  * the transposed layout list[k * row_stride + i], k < count[i], original particle ids: converted from the full
  * CSR of a NL_LIST_FULL build (one coalesced pass), or derived on the device from the half list of a NL_LIST_HALF
@@ -178,7 +203,8 @@ int nl_number_of_pairs(nl_handle_t h, int64_t* npairs);
  * the list: its momentum array is allocated and never used, make_list.cpp:135,138-140).  q_dev: the positions the
  * list was built from (or moved by less than the skin), same dtype and stride; f_dev: n x 4 values of that dtype,
  * {fx, fy, fz, pe_i} with pe_i = half the pair energies of particle i; pairs beyond rc_force (<= the list's cut-off)
- * are skipped; no minimum image, like the list.  After a NL_LIST_FULL build every row gathers its partners and
+ * are skipped; distances are taken as the list took them: between the coordinates as given (open box, the reference's
+ * rule) or, after nl_set_periodic(1), at the minimum image.  After a NL_LIST_FULL build every row gathers its partners and
  * writes its force once; after a NL_LIST_HALF build every pair is evaluated once and the reaction is added to the
  * partner with floating-point atomics (f_dev is zeroed first).  Enqueued on `stream` (NULL = the null stream);
  * waits for the build first. */
@@ -197,9 +223,9 @@ int nl_get_sorted(nl_handle_t h, const int32_t** cell_start_dev, const void** so
 int nl_debug_read(nl_handle_t h, uint64_t* out, int32_t n, int reset);
 int nl_debug_occupancy(int32_t out[8]); /* LDS per CU/block (KiB), occupancy API answers, LDS bytes, registers */
 /* How the last build was organised: info[0] = 1 when the COUNT sweep kept hit masks and the list was expanded from
- * them, 2 when those masks came from the matrix-core search (0: two distance sweeps), info[1] = configured sweep variant, info[2] = LDS batch capacity (particles),
- * info[3] = compute units of the device. */
-int nl_get_build_info(nl_handle_t h, int32_t info[4]);
+ * them (0: two distance sweeps), info[1] = configured sweep variant, info[2] = LDS batch capacity (particles),
+ * info[3] = compute units of the device, info[4] = width of the list offsets the build used (32 / 64), info[5..7] = 0. */
+int nl_get_build_info(nl_handle_t h, int32_t info[8]);
 int nl_last_error(nl_handle_t h);     /* status of the last failed call on this handle */
 int nl_last_hip_error(nl_handle_t h); /* raw hipError_t behind the last NL_ERR_HIP */
 

@@ -32,6 +32,10 @@ PROTOTYPES = {
     "nl_synchronize": (C.c_int, [_P]),
     "nl_get_half_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "nl_get_full_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
+    "nl_get_half_csr64": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
+    "nl_get_full_csr64": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
+    "nl_list_checksum": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(_I64)]),
+    "nl_set_offset_width": (C.c_int, [_P, C.c_int]),
     "nl_lj_forces": (C.c_int, [_P, _P, _I32, _D, _D, _D, _P, _P]),
     "nl_get_full_transposed": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.POINTER(_I32)]),
     "nl_number_of_pairs": (C.c_int, [_P, C.POINTER(_I64)]),
@@ -39,7 +43,7 @@ PROTOTYPES = {
     "nl_get_sorted": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "nl_debug_read": (C.c_int, [_P, C.c_void_p, _I32, C.c_int]),
     "nl_debug_occupancy": (C.c_int, [C.POINTER(_I32 * 8)]),
-    "nl_get_build_info": (C.c_int, [_P, C.POINTER(_I32 * 4)]),
+    "nl_get_build_info": (C.c_int, [_P, C.POINTER(_I32 * 8)]),
     "nl_last_error": (C.c_int, [_P]),
     "nl_last_hip_error": (C.c_int, [_P]),
     "nl_profile_stages": (C.c_int, [_P, _P, _I32, _I32, _I32, C.POINTER(_D * NL_NUM_STAGES)]),

@@ -39,8 +39,6 @@ struct nl_handle_s {
   double ims_d[3];
   float rc2_f = 0;
   float ms_f[3];       // cell edge as the reference's float Vec holds it (neighlist_cpu.hpp:389-391)
-  float mfma_delta = 0;  // k_sweep_mfma_f32: half-width of the band that is re-tested exactly (mfma_delta())
-  double mfma_delta16 = 0, mfma_scale = 1;  // k_sweep_mfma_f16: band (unscaled units) and coordinate scale
 
   int32_t n_max = 0;
   int64_t capacity = 0;      // list entries (half pairs, or twice as many for a full list)
@@ -54,7 +52,10 @@ struct nl_handle_s {
   int32_t* sorted_row = nullptr;
   int32_t* sorted_gid = nullptr;   // ids in cell order, compact
   int32_t* count = nullptr;
-  int32_t* key_pointer = nullptr;
+  void* key_pointer = nullptr;     // [n_rows + 1] int32 (the reference's type, neighlist_cpu.hpp:29) or, in a wide build, int64
+  void* kp_alt = nullptr;          // key_pointer converted to the other width on demand (nl_get_*_csr / nl_get_*_csr64)
+  bool kp_alt_valid = false;
+  int offset_width = 0;            // nl_set_offset_width: 0 = by capacity (int64 as soon as the list may exceed INT32_MAX), 32, 64
   int32_t* progress = nullptr;
   // two-level binning (k_bin_*)
   int32_t* row_count = nullptr;   // [nrows] zeroed per build, then row totals
@@ -64,12 +65,12 @@ struct nl_handle_s {
   int32_t* tmp_row = nullptr;
   int32_t bin_blocks = 0, bin_chunk = 0;
   bool bin_two_level = true;      // NL_BINNING=1 selects the atomic-rank path (k_hash/k_reorder)
-  int32_t* base_sorted = nullptr;  // key_pointer of every sorted slot (persistent sweep, mask expansion)
+  void* base_sorted = nullptr;     // key_pointer of every sorted slot (mask expansion), same width as key_pointer
   uint32_t* masks = nullptr;       // [n][64] hit bits of every sorted slot, between COUNT_MASKS and k_fill_masks
-  int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps; 2: persistent LDS-DMA sweeps (fp32);
-                                   // 3 (default): VALU COUNT keeping hit masks + mask expansion;
-                                   // 4: as 3 with the fp32 COUNT on the matrix cores (k_sweep_mfma_f32; slower so far)
-                                   // 5: as 4 with the f16 two-piece MFMA (k_sweep_mfma_f16)
+  int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps;
+                                   // 3 (default): COUNT keeping hit masks + mask expansion
+                                   // (2 = persistent LDS-DMA sweeps, 4 / 5 = matrix-core searches: measured slower or a draw
+                                   // in round 1 and removed)
   int num_cus = 256;
   unsigned long long* dbg_buf = nullptr;
   int dbg_flags = 0, dbg_wg_per_cu = 4;  // diagnostics (NL_DEBUG_FLAGS, NL_DEBUG_WG_PER_CU)
@@ -99,12 +100,13 @@ struct nl_handle_s {
   struct GraphKey {
     const void* q = nullptr;
     const int32_t* gid = nullptr;
-    int32_t stride = 0, n_rows = 0, n = 0, z_lo = 0, mzl = 0, slab = 0, list_kind = 0, pbc = 0;
+    int32_t stride = 0, n_rows = 0, n = 0, z_lo = 0, mzl = 0, slab = 0, list_kind = 0, pbc = 0, offset_width = 0;
     int64_t capacity = 0;
     uint64_t epoch = 0;
     bool operator==(const GraphKey& o) const {
       return q == o.q && gid == o.gid && stride == o.stride && n_rows == o.n_rows && n == o.n && z_lo == o.z_lo &&
-             mzl == o.mzl && slab == o.slab && list_kind == o.list_kind && pbc == o.pbc && capacity == o.capacity &&
+             mzl == o.mzl && slab == o.slab && list_kind == o.list_kind && pbc == o.pbc && offset_width == o.offset_width &&
+             capacity == o.capacity &&
              epoch == o.epoch;
     }
   } graph_key;
@@ -122,8 +124,9 @@ struct nl_handle_s {
   // arguments of the last build (to re-run the fill after growing the list)
   int32_t b_mzl = 0, b_slab = 0, b_zlo = 0, b_stride = 4;
   bool b_use_masks = false;  // this build: COUNT keeps hit masks and the list is expanded from them
-  bool b_use_mfma = false;   // ... and the masks come from k_sweep_mfma_f32 (layout MASK_TILE16)
+  bool b_wide = false;       // this build: key_pointer / base_sorted hold int64 (the list may exceed INT32_MAX entries)
   bool b_full = false;       // this build: full list (both directions), nl_set_list_kind
+  bool b_pbc = false;        // this build: minimum-image distances (nl_set_periodic)
   int b_variant = 3;         // sweep variant of this build (a full build uses 1 or 3 only)
   const void* b_q = nullptr;
   const int32_t* b_gid = nullptr;
@@ -189,27 +192,28 @@ template <typename T> Grid<T> make_grid(nl_handle_t h, int32_t n_rows, int32_t z
 }
 
 // exclusive scan of in[n] into out[n+1]; grand total to total[0]
-int launch_scan(nl_handle_t h, const int32_t* in, int64_t n, int32_t* out, int64_t* total, hipStream_t s,
+template <typename OFF>
+int launch_scan(nl_handle_t h, const int32_t* in, int64_t n, OFF* out, int64_t* total, hipStream_t s,
                 uint32_t* total_split = nullptr) {
   if (n <= 0) {  // nothing to scan: out[0] = 0, total = 0 (a zero-size grid is not a valid launch)
-    HIPCHK(h, hipMemsetAsync(out, 0, sizeof(int32_t), s));
+    HIPCHK(h, hipMemsetAsync(out, 0, sizeof(OFF), s));
     HIPCHK(h, hipMemsetAsync(total, 0, sizeof(int64_t), s));
     if (total_split) HIPCHK(h, hipMemsetAsync(total_split, 0, 2 * sizeof(uint32_t), s));
     return NL_OK;
   }
   if (n <= SCAN_SMALL_MAX) {  // one launch instead of three (totals of such short arrays fit int32)
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, s, in, (int32_t)n, total, out, total_split);
+    hipLaunchKernelGGL(k_scan_small<OFF>, dim3(1), dim3(1024), 0, s, in, (int32_t)n, total, out, total_split);
     return NL_OK;
   }
   const int32_t nb = (int32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
   hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum);
   if (nb <= SCAN_FUSED_MAX) {  // every block of the down-sweep adds up the block sums before it: one launch less
-    hipLaunchKernelGGL(k_scan_down<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
+    hipLaunchKernelGGL((k_scan_down<true, OFF>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
                        total_split);
     return NL_OK;
   }
   hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, h->block_sum, nb, total);
-  hipLaunchKernelGGL(k_scan_down<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
+  hipLaunchKernelGGL((k_scan_down<false, OFF>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
                      total_split);
   return NL_OK;
 }
@@ -236,15 +240,12 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.count = h->count;
   a.progress = h->progress;
   a.key_pointer = h->key_pointer;
+  a.wide = h->b_wide ? 1 : 0;
   a.list = h->list;
   a.total = h->totals + 1;
   a.capacity = h->capacity;
   a.status = h->status;
   a.masks = h->masks;
-  for (int d = 0; d < 3; d++) a.ms[d] = sizeof(T) == 4 ? (T)h->ms_f[d] : (T)(h->L[d] / h->m[d]);
-  a.delta = (T)h->mfma_delta;
-  a.mf_scale = (T)h->mfma_scale, a.mf_scale2 = (T)(h->mfma_scale * h->mfma_scale);
-  a.delta16 = (T)(h->mfma_delta16 * h->mfma_scale * h->mfma_scale);
   a.pbc = h->pbc ? 1 : 0;
   for (int d = 0; d < 3; d++) a.L[d] = (T)h->L[d];
   a.z_origin = h->b_slab ? h->b_zlo - 1 : 0;
@@ -253,57 +254,30 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   return a;
 }
 
-// FULL = the list keeps both directions of every pair (the reference GPU class's contract); the persistent and
-// matrix-core variants exist for the half list only and are not selected for a full build (enqueue_build).
+// FULL = the list keeps both directions of every pair (the reference GPU class's contract).
+template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(nl_handle_t h, const SweepArgs<T>& a, int32_t ncells_i, hipStream_t s) {
+  const int32_t nbp = (h->n + 255) / 256;
+  if (h->n > 0)
+    hipLaunchKernelGGL(k_row_base<OFF>, dim3(nbp), dim3(256), 0, s, static_cast<const OFF*>(h->key_pointer), h->sorted_row,
+                       h->n_rows, h->n, static_cast<OFF*>(h->base_sorted));
+  hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
+                     static_cast<const OFF*>(h->base_sorted));
+}
+
 template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h, int mode, hipStream_t s) {
   const int32_t owned_layers = h->b_slab ? h->b_mzl - 2 : h->b_mzl;
   const int32_t ncells_i = h->m[0] * h->m[1] * owned_layers;
   const SweepArgs<T> a = sweep_args<T>(h);
-  if constexpr (sizeof(T) == 4 && !FULL && !PBC) {
-    if (h->b_variant == 2) {
-      // persistent kernel: 4 workgroups of 8 waves per CU (2 x 20 KiB LDS each), each walking a run of cells
-      const int32_t grid = std::max(8, std::min(h->dbg_wg_per_cu * h->num_cus, (ncells_i + 1) / 2 / 8 * 8));
-      if (mode == MODE_COUNT) {
-        hipLaunchKernelGGL((k_sweep_p<T, MODE_COUNT>), dim3(grid), dim3(PW * WAVE), 0, s, a, ncells_i, nullptr,
-                           h->cell_count + h->ncell + 1);
-      } else {
-        const int32_t nbp = (h->n + 255) / 256;
-        if (h->n > 0)
-          hipLaunchKernelGGL(k_row_base, dim3(nbp), dim3(256), 0, s, h->key_pointer, h->sorted_row, h->n_rows, h->n,
-                             h->base_sorted);
-        hipLaunchKernelGGL((k_sweep_p<T, MODE_FILL>), dim3(grid), dim3(PW * WAVE), 0, s, a, ncells_i, h->base_sorted,
-                           h->cell_count + h->ncell + 1 + 8);
-      }
-      return;
-    }
-  }
   if (h->b_use_masks) {
     if (mode == MODE_COUNT) {
-      if constexpr (sizeof(T) == 4) {
-        if constexpr (FULL && !PBC) {
-          if (h->b_use_mfma && h->b_variant == 5) {
-            hipLaunchKernelGGL(k_sweep_mfma_f16_full, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
-            return;
-          }
-        }
-        if constexpr (!FULL && !PBC) {
-          if (h->b_use_mfma) {
-            if (h->b_variant == 5)
-              hipLaunchKernelGGL(k_sweep_mfma_f16, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
-            else
-              hipLaunchKernelGGL(k_sweep_mfma_f32, dim3(ncells_i), dim3(MF_WAVES * WAVE), 0, s, a);
-            return;
-          }
-        }
+      if constexpr (sizeof(T) == 4)
         hipLaunchKernelGGL((k_sweep_count_masks_f32<FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), h->dbg_lds_pad, s, a);
-      } else
+      else
         hipLaunchKernelGGL((k_sweep<T, MODE_COUNT_MASKS, FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+    } else if (h->b_wide) {
+      launch_fill_masks<T, FULL, PBC, int64_t>(h, a, ncells_i, s);
     } else {
-      const int32_t nbp = (h->n + 255) / 256;
-      if (h->n > 0)
-        hipLaunchKernelGGL(k_row_base, dim3(nbp), dim3(256), 0, s, h->key_pointer, h->sorted_row, h->n_rows, h->n,
-                           h->base_sorted);
-      hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a, h->base_sorted);
+      launch_fill_masks<T, FULL, PBC, int32_t>(h, a, ncells_i, s);
     }
     return;
   }
@@ -331,25 +305,34 @@ template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) 
 // the binning pass over [0, n_rows)); PART_FINISH = the rest (the binning pass over the ghosts, search, scan,
 // expansion).  BEGIN + FINISH = ALL for the caller; between the two the halo exchange may still be writing the ghosts.
 enum { PART_ALL = 0, PART_BEGIN = 1, PART_FINISH = 2 };
+
+// What the handle remembers about the build being enqueued (also set when a captured graph of it is replayed): how the
+// later stages, the getters and a refill after growth have to read the buffers.
+template <typename T>
+void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int32_t* gid, int32_t n, int32_t z_lo,
+                     int32_t mzl, int32_t slab) {
+  const int64_t ncl = (int64_t)h->m[0] * h->m[1] * mzl;
+  h->ncell_local = ncl;
+  h->b_mzl = mzl, h->b_slab = slab, h->b_zlo = z_lo, h->b_stride = stride, h->b_q = q_dev, h->b_gid = gid;
+  h->b_full = h->list_kind == NL_LIST_FULL;
+  h->b_pbc = h->pbc;
+  h->b_variant = h->sweep_variant;
+  // Hit masks pay off while a cell's stencil fits one LDS batch; where the mean stencil (27 cells) is close to or
+  // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
+  h->b_use_masks = h->b_variant >= 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
+  // 64-bit list offsets as soon as the list this handle can hold exceeds what an int32 key_pointer can address
+  // (the reference's own limit, neighlist_cpu.hpp:15,29); nl_set_offset_width overrides.
+  h->b_wide = h->offset_width == 64 || (h->offset_width == 0 && h->capacity > 2147483647LL);
+  h->kp_alt_valid = false;
+}
+
 template <typename T>
 int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_t* gid, int32_t n_rows, int32_t n,
                   int32_t z_lo, int32_t mzl, int32_t slab, hipStream_t s, hipEvent_t* ev, int part = PART_ALL,
                   int32_t n_ghost_lo = 0) {
   const Grid<T> g = make_grid<T>(h, n_rows, z_lo, mzl, slab);
   const int64_t ncl = (int64_t)h->m[0] * h->m[1] * mzl;
-  h->ncell_local = ncl;
-  h->b_mzl = mzl, h->b_slab = slab, h->b_zlo = z_lo, h->b_stride = stride, h->b_q = q_dev, h->b_gid = gid;
-  // Hit masks pay off while a cell's stencil fits one LDS batch; where the mean stencil (27 cells) is close to or
-  // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
-  h->b_full = h->list_kind == NL_LIST_FULL;
-  // (the persistent and matrix-core variants implement the reference's open-box distances and the half list only)
-  h->b_variant = (h->b_full || h->pbc) ? (h->sweep_variant >= 3 ? 3 : 1) : h->sweep_variant;
-  // Full list, open box: the f16 matrix-core search has a full-list form (no id test per pair), opt-in like the other
-  // matrix-core variants (NL_SWEEP_VARIANT=5): the north star of this path asks for a VALU search, and the default
-  // stays one.  Measured: COUNT 272 against 308 us at cfg 2 (39 particles per cell), even at 29, 291 against 230 at 19.
-  if (h->b_full && !h->pbc && h->sweep_variant == 5) h->b_variant = 5;
-  h->b_use_masks = h->b_variant >= 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
-  h->b_use_mfma = h->b_use_masks && h->b_variant >= 4 && sizeof(T) == 4;
+  set_build_state<T>(h, q_dev, stride, gid, n, z_lo, mzl, slab);
   const int32_t nbp = (n + 255) / 256;
   const T* q = static_cast<const T*>(q_dev);
 
@@ -359,7 +342,7 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   // what this build's path needs (histogram + meta, or meta + row totals).
   // two binning passes: owned, then ghosts (the persistent sweep, variant 2, has its own cell walk without the guard
   // against an inconsistent cell table: no split there)
-  const bool split = part != PART_ALL && two_level && slab && h->sweep_variant != 2;
+  const bool split = part != PART_ALL && two_level && slab;
   if (part != PART_ALL && !split) {  // nothing to overlap on this path: BEGIN does nothing, FINISH is the whole build
     if (part == PART_BEGIN) return NL_OK;
     part = PART_ALL;
@@ -413,7 +396,11 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
   // (rows of particles rejected by the hash keep a stale count: such a build fails with its status anyway)
   launch_sweep<T>(h, MODE_COUNT, s);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_ROW_SCAN], s));
-  if (int rc = launch_scan(h, h->count, n_rows, h->key_pointer, h->totals + 1, s, h->status + META_TOTAL)) return rc;
+  if (h->b_wide) {
+    if (int rc = launch_scan(h, h->count, n_rows, static_cast<int64_t*>(h->key_pointer), h->totals + 1, s, h->status + META_TOTAL)) return rc;
+  } else {
+    if (int rc = launch_scan(h, h->count, n_rows, static_cast<int32_t*>(h->key_pointer), h->totals + 1, s, h->status + META_TOTAL)) return rc;
+  }
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_FILL], s));
   launch_sweep<T>(h, MODE_FILL, s);
   if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_TOTAL], s));
@@ -450,6 +437,8 @@ int estimate_capacity(nl_handle_t h) {
 
 int grow_list(nl_handle_t h, int64_t need) {
   int64_t cap = std::max<int64_t>(need + need / 8 + 1024, h->capacity);
+  // a list that an int32 key_pointer can still address stays below the switch to 64-bit offsets
+  if (need <= 2147483647LL && cap > 2147483647LL && h->capacity <= 2147483647LL) cap = 2147483647LL;
   int rc = dev_alloc(h, &h->list, sizeof(int32_t) * (size_t)cap);
   if (rc) {
     h->capacity = 0;
@@ -465,7 +454,17 @@ int finish(nl_handle_t h, bool may_grow) {
   HIPCHK(h, hipStreamSynchronize(h->last_stream));
   h->pending = false;
   uint32_t st = h->host->status;
-  if ((st & ST_CAPACITY) && !(st & ~ST_CAPACITY) && may_grow) {
+  if ((st & ST_INDEX_OVERFLOW) && !(st & ~(ST_CAPACITY | ST_INDEX_OVERFLOW)) && may_grow && !h->b_wide && h->offset_width == 0) {
+    // more than INT32_MAX entries in a build with 32-bit offsets: the list grows past that size, which makes builds of
+    // this handle wide (64-bit key_pointer), and the whole build runs again
+    int rc = grow_list(h, h->host->total());
+    if (rc) return rc;
+    rc = dispatch_build(h, h->b_q, h->b_stride, h->b_gid, h->n_rows, h->n, h->b_zlo, h->b_mzl, h->b_slab, h->last_stream, nullptr);
+    if (!rc) rc = enqueue_result_copy(h, h->last_stream);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->last_stream));
+    st = h->host->status;
+  } else if ((st & ST_CAPACITY) && !(st & ~ST_CAPACITY) && may_grow) {
     int rc = grow_list(h, h->host->total());
     if (rc) return rc;
     HIPCHK(h, hipMemsetAsync(h->status, 0, sizeof(uint32_t), h->last_stream));
@@ -486,6 +485,95 @@ int finish(nl_handle_t h, bool may_grow) {
 
 }  // namespace
 
+namespace {
+template <typename SRC, typename DST>
+__global__ void __launch_bounds__(256) k_convert_offsets(const SRC* __restrict__ in, DST* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (DST)in[i];
+}
+
+// key_pointer of the last build in the requested width (32 or 64): the buffer the build wrote when the widths agree,
+// else a converted copy made once per build.  A wide list that an int32 cannot address is NL_ERR_INDEX_OVERFLOW.
+int key_pointer_as(nl_handle_t h, int width, const void** out) {
+  const bool want_wide = width == 64;
+  if (want_wide == h->b_wide) {
+    *out = h->key_pointer;
+    return NL_OK;
+  }
+  if (!want_wide && h->host->total() > 2147483647LL) return fail(h, NL_ERR_INDEX_OVERFLOW);
+  const int64_t cnt = (int64_t)h->n_rows + 1;
+  if (!h->kp_alt) {
+    HIPCHK(h, hipSetDevice(h->device));
+    void* p = nullptr;
+    if (hipMalloc(&p, 8 * ((size_t)h->n_max + 32)) != hipSuccess) return fail(h, NL_ERR_NOMEM);
+    h->kp_alt = p;
+    h->kp_alt_valid = false;
+  }
+  if (!h->kp_alt_valid) {
+    const int32_t nb = (int32_t)((cnt + 255) / 256);
+    if (want_wide)
+      hipLaunchKernelGGL((k_convert_offsets<int32_t, int64_t>), dim3(nb), dim3(256), 0, h->last_stream,
+                         static_cast<const int32_t*>(h->key_pointer), static_cast<int64_t*>(h->kp_alt), cnt);
+    else
+      hipLaunchKernelGGL((k_convert_offsets<int64_t, int32_t>), dim3(nb), dim3(256), 0, h->last_stream,
+                         static_cast<const int64_t*>(h->key_pointer), static_cast<int32_t*>(h->kp_alt), cnt);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->last_stream));
+    h->kp_alt_valid = true;
+  }
+  *out = h->kp_alt;
+  return NL_OK;
+}
+
+// Order-independent checksum of the list: sum over entries (row i, partner j) of mix((id_i << 32) | j), mix(v): v *= 0x9E3779B97F4A7C15,
+// v ^= v >> 29 (wrapping) -- the pair-set hash the known answers of SURVEY.md section 8c are stored as.  One wave per row at a time.
+template <typename T, typename OFF>
+__global__ void __launch_bounds__(256) k_list_checksum(const OFF* __restrict__ kp, const int32_t* __restrict__ list, int32_t n_rows,
+                                                       const int32_t* __restrict__ gid, const T* __restrict__ q,
+                                                       unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long part[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long h = 0;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < n_rows; row += (int64_t)gridDim.x * 4) {
+    uint32_t id = (uint32_t)row;
+    if (gid == reinterpret_cast<const int32_t*>(1)) {  // NL_GID_IN_W
+      if constexpr (sizeof(T) == 4) id = (uint32_t)__float_as_int(q[(size_t)row * 4 + 3]);
+      else id = (uint32_t)__double_as_longlong(q[(size_t)row * 4 + 3]);
+    } else if (gid) {
+      id = (uint32_t)gid[row];
+    }
+    const OFF b = kp[row], e = kp[row + 1];
+    for (OFF k = b + lane; k < e; k += 64) {
+      unsigned long long v = ((unsigned long long)id << 32) | (uint32_t)list[k];
+      v *= 0x9E3779B97F4A7C15ULL;
+      v ^= v >> 29;
+      h += v;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d, 64);
+  if (lane == 0) part[w] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+int get_csr(nl_handle_t h, bool full, int width, const void** key_pointer_dev, const int32_t** list_dev,
+            const int32_t** number_of_partners_dev, int64_t* nentries) {
+  if (!h) return NL_ERR_ARG;
+  int rc = nl_synchronize(h);
+  if (rc) return rc;
+  if (h->b_full != full) return fail(h, NL_ERR_STATE);
+  if (key_pointer_dev)
+    if ((rc = key_pointer_as(h, width, key_pointer_dev))) return rc;
+  if (!key_pointer_dev && width == 32 && h->host->total() > 2147483647LL) return fail(h, NL_ERR_INDEX_OVERFLOW);
+  if (list_dev) *list_dev = h->list;
+  if (number_of_partners_dev) *number_of_partners_dev = h->count;
+  if (nentries) *nentries = h->host->total();
+  return NL_OK;
+}
+}  // namespace
+
+
 extern "C" {
 
 const char* nl_status_string(int s) {
@@ -498,7 +586,7 @@ const char* nl_status_string(int s) {
     case NL_ERR_HIP: return "HIP runtime error";
     case NL_ERR_STATE: return "call order violated";
     case NL_ERR_MESH: return "fewer than 3 cells along an axis";
-    case NL_ERR_INDEX_OVERFLOW: return "more than INT32_MAX pairs";
+    case NL_ERR_INDEX_OVERFLOW: return "more than INT32_MAX list entries behind a 32-bit key_pointer";
     case NL_ERR_NO_DEVICE: return "no usable HIP device";
     case NL_ERR_DOMAIN: return "particle outside the layers declared for this rank";
     default: return "unknown status";
@@ -547,25 +635,6 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     const double ms_d = L[d] / m[d];
     h->ims_d[d] = 1.0 / ms_d;
   }
-  {
-    // k_sweep_mfma_f32 decides a pair from acc = (|ui|^2 - rc2) + |uj|^2 - 2 ui.uj (local coordinates u, matrix
-    // core) only where |acc| >= delta.  For a pair within a factor 4 of the cut-off every term is bounded by
-    // S = (|ui| + |uj|)^2 <= (cell diagonal + rc)^2 (|ui| <= half the diagonal, |uj| <= |ui| + rc): about eight
-    // roundings of relative size 2^-24 on terms <= S, plus the rounding of the local coordinates and of the
-    // reference's own r2, stay below 2^-20.5 S; delta = 2^-18 S leaves a factor 5.  Farther pairs are decided by
-    // a margin of >= 0.15 S' against an error of 1e-6 S' (S' their own term bound).
-    double diag2 = 0;
-    for (int d = 0; d < 3; d++) diag2 += (double)h->ms_f[d] * h->ms_f[d];
-    const double S = (std::sqrt(diag2) + rc) * (std::sqrt(diag2) + rc);
-    h->mfma_delta = (float)(S / 262144.0);
-    // f16 form: the two-piece split (top 11 bits + 11 truncated bits) represents a coordinate to 2^-21 relative, four
-    // times coarser than fp32: the same budget with that term four times larger stays below 2^-19.5 S; delta16 =
-    // 2^-17 S.  Scale: the largest power of two that keeps 2 max(ms) * scale <= 96, so that every particle of the
-    // 27 cells has |u|^2 scale^2 <= 3 * 72^2 < 60000 (the far-sentinel threshold, below the f16 maximum 65504).
-    h->mfma_delta16 = S / 131072.0;
-    const double umax = 2.0 * std::max(h->ms_f[0], std::max(h->ms_f[1], h->ms_f[2]));
-    h->mfma_scale = std::exp2(std::floor(std::log2(96.0 / umax)));
-  }
   h->ncell = (int64_t)m[0] * m[1] * m[2];
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&h->host), sizeof(HostResult), hipHostMallocDefault) != hipSuccess) {
@@ -581,7 +650,8 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
-    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = std::min(5, std::max(1, atoi(v)));
+    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : 3;
+    if (const char* v = getenv("NL_OFFSET_WIDTH")) h->offset_width = atoi(v) == 64 ? 64 : atoi(v) == 32 ? 32 : 0;
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_GRAPH")) h->use_graph = atoi(v) != 0;
     if (const char* v = getenv("NL_DEBUG_FLAGS")) h->dbg_flags = atoi(v);
@@ -596,7 +666,7 @@ int nl_destroy(nl_handle_t h) {
   if (!h) return NL_ERR_ARG;
   (void)hipSetDevice(h->device);
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
-  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->dbg_buf, h->cell_count,
+  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->kp_alt, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->dbg_buf, h->cell_count,
                   h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -626,9 +696,11 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   if ((rc = dev_alloc(h, &h->sorted_row, 4 * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->sorted_gid, 4 * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->count, 4 * (n + 32)))) return rc;
-  if ((rc = dev_alloc(h, &h->key_pointer, 4 * (n + 32)))) return rc;
+  if ((rc = dev_alloc(h, &h->key_pointer, 8 * (n + 32)))) return rc;  // int32 or int64 offsets (b_wide)
+  if (h->kp_alt) (void)hipFree(h->kp_alt), h->kp_alt = nullptr;
+  h->kp_alt_valid = false;
   if ((rc = dev_alloc(h, &h->progress, 4 * (n + 16)))) return rc;
-  if ((rc = dev_alloc(h, &h->base_sorted, 4 * (n + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->base_sorted, 8 * (n + 16)))) return rc;
   {
     const size_t nrows = (size_t)h->m[1] * h->m[2];
     // chunk per block: 4096 particles, more for very large N so that blk_base stays small
@@ -716,6 +788,9 @@ int make_list_slab_part(nl_handle_t h, const void* q_dev, int32_t q_stride, cons
   if (!h) return NL_ERR_ARG;
   if (part == PART_FINISH) {
     if (!h->begun) return fail(h, NL_ERR_STATE);
+    // the second half reuses what the first half is still writing (row totals, the owned region of the sorted array):
+    // it must be ordered behind it, i.e. enqueued on the same stream
+    if ((hipStream_t)stream != h->last_stream) return fail(h, NL_ERR_STATE);
     q_dev = h->b_q, q_stride = h->b_stride, gid_dev = h->b_gid, n_rows = h->n_rows, n = h->n, n_ghost_lo = h->begun_ghost_lo;
     z_lo = h->begun_zlo, z_hi = h->begun_zhi;
   }
@@ -761,7 +836,7 @@ int make_list_slab_part(nl_handle_t h, const void* q_dev, int32_t q_stride, cons
     nl_handle_s::GraphKey key;
     key.q = q_dev, key.gid = gid_dev, key.stride = q_stride, key.n_rows = n_rows, key.n = n, key.z_lo = z_lo, key.mzl = mzl;
     key.slab = slab, key.list_kind = h->list_kind, key.pbc = h->pbc ? 1 : 0, key.capacity = h->capacity;
-    key.epoch = h->buffers_epoch;
+    key.epoch = h->buffers_epoch, key.offset_width = h->offset_width;
     if (!h->graph_exec || !(key == h->graph_key)) {
       if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec), h->graph_exec = nullptr;
       if (h->graph) (void)hipGraphDestroy(h->graph), h->graph = nullptr;
@@ -779,6 +854,10 @@ int make_list_slab_part(nl_handle_t h, const void* q_dev, int32_t q_stride, cons
       h->graph = g;
       HIPCHK(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
       h->graph_key = key;
+    }
+    else {  // replay: the handle's per-build state is the captured build's, whatever ran in between
+      if (h->dtype == NL_F32) set_build_state<float>(h, q_dev, q_stride, gid_dev, n, z_lo, mzl, slab);
+      else set_build_state<double>(h, q_dev, q_stride, gid_dev, n, z_lo, mzl, slab);
     }
     HIPCHK(h, hipGraphLaunch(h->graph_exec, s));
   } else {
@@ -822,27 +901,63 @@ int nl_synchronize(nl_handle_t h) {
 
 int nl_get_full_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_t** list_dev,
                     const int32_t** number_of_partners_dev, int64_t* nentries) {
-  if (!h) return NL_ERR_ARG;
-  int rc = nl_synchronize(h);
-  if (rc) return rc;
-  if (!h->b_full) return fail(h, NL_ERR_STATE);
-  if (key_pointer_dev) *key_pointer_dev = h->key_pointer;
-  if (list_dev) *list_dev = h->list;
-  if (number_of_partners_dev) *number_of_partners_dev = h->count;
-  if (nentries) *nentries = h->host->total();
-  return NL_OK;
+  return get_csr(h, true, 32, reinterpret_cast<const void**>(key_pointer_dev), list_dev, number_of_partners_dev, nentries);
 }
 
 int nl_get_half_csr(nl_handle_t h, const int32_t** key_pointer_dev, const int32_t** sorted_list_dev,
                     const int32_t** number_of_partners_dev, int64_t* npairs) {
-  if (!h) return NL_ERR_ARG;
+  return get_csr(h, false, 32, reinterpret_cast<const void**>(key_pointer_dev), sorted_list_dev, number_of_partners_dev, npairs);
+}
+
+int nl_get_full_csr64(nl_handle_t h, const int64_t** key_pointer_dev, const int32_t** list_dev,
+                      const int32_t** number_of_partners_dev, int64_t* nentries) {
+  return get_csr(h, true, 64, reinterpret_cast<const void**>(key_pointer_dev), list_dev, number_of_partners_dev, nentries);
+}
+
+int nl_get_half_csr64(nl_handle_t h, const int64_t** key_pointer_dev, const int32_t** sorted_list_dev,
+                      const int32_t** number_of_partners_dev, int64_t* npairs) {
+  return get_csr(h, false, 64, reinterpret_cast<const void**>(key_pointer_dev), sorted_list_dev, number_of_partners_dev, npairs);
+}
+
+int nl_list_checksum(nl_handle_t h, uint64_t* checksum, int64_t* nentries) {
+  if (!h || !checksum) return fail(h, NL_ERR_ARG);
   int rc = nl_synchronize(h);
   if (rc) return rc;
-  if (h->b_full) return fail(h, NL_ERR_STATE);
-  if (key_pointer_dev) *key_pointer_dev = h->key_pointer;
-  if (sorted_list_dev) *sorted_list_dev = h->list;
-  if (number_of_partners_dev) *number_of_partners_dev = h->count;
-  if (npairs) *npairs = h->host->total();
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->last_stream;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(h->totals + 3);
+  HIPCHK(h, hipMemsetAsync(acc, 0, 8, s));
+  const int32_t n = h->n_rows;
+  if (n > 0) {
+    const int32_t grid = std::max(1, std::min((n + 3) / 4, 8 * h->num_cus));
+    const bool w = h->b_wide, f32 = h->dtype == NL_F32;
+    if (f32 && !w)
+      hipLaunchKernelGGL((k_list_checksum<float, int32_t>), dim3(grid), dim3(256), 0, s, static_cast<const int32_t*>(h->key_pointer), h->list, n, h->b_gid, static_cast<const float*>(h->b_q), acc);
+    else if (f32)
+      hipLaunchKernelGGL((k_list_checksum<float, int64_t>), dim3(grid), dim3(256), 0, s, static_cast<const int64_t*>(h->key_pointer), h->list, n, h->b_gid, static_cast<const float*>(h->b_q), acc);
+    else if (!w)
+      hipLaunchKernelGGL((k_list_checksum<double, int32_t>), dim3(grid), dim3(256), 0, s, static_cast<const int32_t*>(h->key_pointer), h->list, n, h->b_gid, static_cast<const double*>(h->b_q), acc);
+    else
+      hipLaunchKernelGGL((k_list_checksum<double, int64_t>), dim3(grid), dim3(256), 0, s, static_cast<const int64_t*>(h->key_pointer), h->list, n, h->b_gid, static_cast<const double*>(h->b_q), acc);
+    HIPCHK(h, hipGetLastError());
+  }
+  unsigned long long out = 0;
+  HIPCHK(h, hipMemcpyAsync(&out, acc, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  *checksum = (uint64_t)out;
+  if (nentries) *nentries = h->host->total();
+  return NL_OK;
+}
+
+int nl_set_offset_width(nl_handle_t h, int bits) {
+  if (!h || (bits != 0 && bits != 32 && bits != 64)) return fail(h, NL_ERR_ARG);
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->pending) (void)finish(h, false);
+  if (bits != h->offset_width) {
+    h->offset_width = bits;
+    h->built = false;
+    h->t_valid = false;
+  }
   return NL_OK;
 }
 
@@ -889,24 +1004,23 @@ int nl_debug_occupancy(int32_t out[8]) {
   if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return NL_ERR_NO_DEVICE;
   out[0] = (int32_t)(prop.maxSharedMemoryPerMultiProcessor / 1024);
   out[1] = (int32_t)(prop.sharedMemPerBlock / 1024);
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_p<float, MODE_COUNT>, PW * WAVE, 0);
-  out[2] = v;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_p<float, MODE_FILL>, PW * WAVE, 0);
-  out[3] = v;
+  out[2] = out[3] = 0;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep_count_f32<false, false>, SWEEP_WAVES * WAVE, 0);
   out[4] = v;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_sweep<float, MODE_FILL>, SWEEP_WAVES * WAVE, 0);
   out[5] = v;
   hipFuncAttributes fa;
-  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_sweep_p<float, MODE_COUNT>));
+  (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_sweep_count_masks_f32<false, false>));
   out[6] = (int32_t)fa.sharedSizeBytes;
   out[7] = fa.numRegs;
   return NL_OK;
 }
 
-int nl_get_build_info(nl_handle_t h, int32_t info[4]) {
+int nl_get_build_info(nl_handle_t h, int32_t info[8]) {
   if (!h || !info) return NL_ERR_ARG;
-  info[0] = h->b_use_mfma ? 2 : h->b_use_masks ? 1 : 0;
+  for (int k = 4; k < 8; k++) info[k] = 0;
+  info[4] = h->b_wide ? 64 : 32;
+  info[0] = h->b_use_masks ? 1 : 0;
   info[1] = h->sweep_variant;
   info[2] = h->dtype == NL_F32 ? SweepCfg<float>::CAP : SweepCfg<double>::CAP;
   info[3] = h->num_cus;

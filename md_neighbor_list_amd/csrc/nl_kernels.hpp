@@ -262,15 +262,17 @@ __global__ void __launch_bounds__(1024) k_scan_spine(int64_t* __restrict__ block
   if (tid == 0) total[0] = carry_s;
 }
 
-// out[i] = exclusive prefix (int32); out[n] = total.  Flags ST_INDEX_OVERFLOW when the total exceeds INT32_MAX.
+// out[i] = exclusive prefix; out[n] = total.  OFF = int32_t (the reference's key_pointer type, neighlist_cpu.hpp:15,29):
+// flags ST_INDEX_OVERFLOW when the total exceeds INT32_MAX; OFF = int64_t (wide builds: lists beyond 2^31 entries,
+// BASELINE config 4 on one device) never overflows.
 // FUSED (up to SCAN_FUSED_MAX blocks): block_off holds the RAW block sums of k_scan_reduce; every block adds up the
 // sums before it itself (<= 8 KiB of reads) and the last block publishes the grand total -- no spine launch.
 constexpr int SCAN_FUSED_MAX = 1024;
-template <bool FUSED>
+template <bool FUSED, typename OFF>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __restrict__ in, int64_t n,
                                                              const int64_t* __restrict__ block_off,
                                                              int64_t* __restrict__ total,
-                                                             int32_t* __restrict__ out,
+                                                             OFF* __restrict__ out,
                                                              uint32_t* __restrict__ status,
                                                              uint32_t* __restrict__ total_split) {
   __shared__ int32_t wsum[SCAN_THREADS / WAVE];
@@ -301,16 +303,16 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
   } else {
     my_off = block_off[blockIdx.x];
   }
-  int32_t run = (int32_t)my_off + woff + inc - s;
-  if (base + SCAN_ITEMS <= n) {
+  OFF run = (OFF)my_off + (OFF)(woff + inc - s);
+  if (sizeof(OFF) == 4 && base + SCAN_ITEMS <= n) {
     int4* p = reinterpret_cast<int4*>(out + base);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS / 4; k++) {
       int4 a;
-      a.x = run, run += v[4 * k];
-      a.y = run, run += v[4 * k + 1];
-      a.z = run, run += v[4 * k + 2];
-      a.w = run, run += v[4 * k + 3];
+      a.x = (int32_t)run, run += v[4 * k];
+      a.y = (int32_t)run, run += v[4 * k + 1];
+      a.z = (int32_t)run, run += v[4 * k + 2];
+      a.w = (int32_t)run, run += v[4 * k + 3];
       p[k] = a;
     }
   } else {
@@ -323,8 +325,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
   if (FUSED ? (blockIdx.x == gridDim.x - 1 && tid == 0) : (blockIdx.x == 0 && tid == 0)) {
     const int64_t t = FUSED ? my_off + block_off[blockIdx.x] : total[0];
     if (FUSED) total[0] = t;
-    out[n] = (int32_t)t;
-    if (t > 2147483647LL) atomicOr(status, ST_INDEX_OVERFLOW);
+    out[n] = (OFF)t;
+    if (sizeof(OFF) == 4 && t > 2147483647LL) atomicOr(status, ST_INDEX_OVERFLOW);
     if (total_split) {  // the grand total next to the status word: one small device->host copy per build
       total_split[0] = (uint32_t)t;
       total_split[1] = (uint32_t)((unsigned long long)t >> 32);
@@ -335,8 +337,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
 // Same scan for short arrays in ONE launch (small boxes: a few thousand cells): a
 // single workgroup, every thread scans a contiguous run of K items, the 1024 run totals are scanned through LDS.
 constexpr int SCAN_SMALL_MAX = 4096;  // beyond that the per-thread runs get long and the three-kernel scan is faster
+template <typename OFF>
 __global__ void __launch_bounds__(1024) k_scan_small(const int32_t* __restrict__ in, int32_t n,
-                                                      int64_t* __restrict__ total, int32_t* __restrict__ out,
+                                                      int64_t* __restrict__ total, OFF* __restrict__ out,
                                                       uint32_t* __restrict__ total_split) {
   __shared__ int32_t wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -612,7 +615,8 @@ template <typename T> struct SweepArgs {
   T rc2;                          // largest T value <= rc*rc in double, so !(r2 > rc2) == !((double)r2 > rc2_double)
   int32_t* __restrict__ count;    // [n_rows] number_of_partners (COUNT writes, FILL reads nothing from it)
   int32_t* __restrict__ progress; // [n_rows] scratch, only touched when a stencil needs more than one LDS batch
-  const int32_t* __restrict__ key_pointer;
+  const void* __restrict__ key_pointer;  // [n_rows + 1] int32 offsets, or int64 when `wide`
+  int32_t wide;                   // this build's list may exceed 2^31 entries: key_pointer / base_sorted hold int64
   int32_t* __restrict__ list;
   const int64_t* __restrict__ total;
   int64_t capacity;
@@ -620,9 +624,6 @@ template <typename T> struct SweepArgs {
   T L[3];                         // box lengths rounded to T (minimum-image mode)
   int32_t pbc;                    // minimum-image mode: stencil cells reached through the periodic wrap are staged
                                   // at their image, coordinate -+ L (nl_set_periodic; not in the reference)
-  T ms[3];                        // cell edge rounded to T (neighlist_cpu.hpp:404-406); k_sweep_mfma_f32 only
-  T delta;                        // k_sweep_mfma_f32: |r2 - rc2| below this is re-tested exactly
-  T delta16, mf_scale, mf_scale2; // k_sweep_mfma_f16: the band in scaled units, the power-of-two scale and its square
   int32_t z_origin;               // global z layer of local layer 0
   uint32_t* __restrict__ masks;  // [n] rows of 64 x 24 bits (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
@@ -664,13 +665,14 @@ constexpr int NSEG = 18;
 // stream position self0 + k, is taken out of the word and of the count once at the end.
 template <typename T, int MODE, int GC, bool FULL = false, bool NOSELF = false>
 __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos<T>* tile, int32_t nj,
-                                                int32_t ntiles, int lane, const Pos<T>& pi_l, int32_t base_l,
+                                                int32_t ntiles, int lane, const Pos<T>& pi_l, int64_t base_l,
                                                 int32_t slot0 = 0, bool store_masks = false, int32_t self0 = 0) {
   static_assert(!NOSELF || (FULL && MODE == MODE_COUNT_MASKS), "NOSELF is a form of the full-list COUNT_MASKS search");
   static_assert(SweepCfg<T>::CAP / WAVE <= 24, "one bit per j-tile in the 24-bit word a lane keeps (mask_store)");
   T xi[GC], yi[GC], zi[GC];
   int32_t gi[GC];
-  uint32_t cur[GC];  // COUNT: hits so far; FILL: list offset of the row + hits so far
+  uint32_t cur[GC];  // hits so far
+  int32_t* rowp[GC];  // FILL: where the row's next entry goes (wave-uniform 64-bit pointer: the list may exceed 2^31 entries)
   uint32_t bits[GC];  // COUNT_MASKS: bit t of lane l = staged particle t*64 + l accepted
 #pragma unroll
   for (int k = 0; k < GC; k++) bits[k] = 0;
@@ -686,7 +688,12 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
       zi[k] = __shfl(pi_l.z, k, WAVE);
     }
     gi[k] = __builtin_amdgcn_readlane(pi_l.gid, k);
-    cur[k] = MODE == MODE_FILL ? (uint32_t)__builtin_amdgcn_readlane(base_l, k) : 0u;
+    cur[k] = 0u;
+    if (MODE == MODE_FILL) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)base_l, k);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)((uint64_t)base_l >> 32), k);
+      rowp[k] = a.list + (int64_t)(((uint64_t)hi << 32) | lo);
+    }
   }
 
   // One tile of 64 staged j-particles (lanes) against the GC i-particles (SGPRs).  All vector work of the GC
@@ -711,11 +718,11 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
         if (hit[k]) {
           const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask[k] >> 32),
                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask[k], 0u));
-          // uniform 64-bit base + 32-bit byte offset (global_store saddr form); the host keeps capacity < 2^30.
-          // cur[k] = list offset of the row + entries written so far
-          const uint32_t boff = (cur[k] + pre) << 2;
-          *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + boff) = pj.gid;
+          // uniform 64-bit row pointer (SGPR pair) + the lane's 32-bit place among this tile's hits: the
+          // global_store saddr form, valid for any list size
+          rowp[k][pre] = pj.gid;
         }
+        rowp[k] += __popcll(mask[k]);
       }
       if (MODE == MODE_COUNT_MASKS) {
         // bits = 2 bits + hit in ONE vector instruction: add-with-carry of the word to itself, the carry-in being the
@@ -757,7 +764,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   uint32_t mine = 0;
 #pragma unroll
   for (int k = 0; k < GC; k++) mine = lane == k ? cur[k] : mine;
-  return (int32_t)(MODE == MODE_FILL ? mine - (uint32_t)base_l : mine);
+  return (int32_t)mine;
 }
 
 // Everything a workgroup knows about its i-cell: the cell's own particles [ibeg, ibeg + ni) and, per lane
@@ -904,11 +911,13 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       // lane k < gcount holds i-particle k of the group
       Pos<T> pi_l;
       pi_l.x = 0, pi_l.y = 0, pi_l.z = 0, pi_l.gid = 0;
-      int32_t row_l = 0, base_l = 0;
+      int32_t row_l = 0;
+      int64_t base_l = 0;
       if (lane < gcount) {
         pi_l = a.sorted[ibeg + i0 + lane];
         row_l = a.sorted_row[ibeg + i0 + lane];
-        if (MODE == MODE_FILL) base_l = a.key_pointer[row_l];
+        if (MODE == MODE_FILL)
+          base_l = a.wide ? static_cast<const int64_t*>(a.key_pointer)[row_l] : (int64_t)static_cast<const int32_t*>(a.key_pointer)[row_l];
         if (batch) base_l += a.progress[row_l];  // entries already produced by earlier batches
       }
       const int32_t slot0 = ibeg + i0;
@@ -1004,9 +1013,9 @@ __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan ov
 template <bool FULL> constexpr int EXPAND_RMAX_OF = FULL ? 192 : 160;
 constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
 
-template <typename T, bool FULL = false, bool PBC = false>
-__global__ void __launch_bounds__(EXPAND_WAVES* WAVE, (sizeof(T) == 4 ? (FULL ? 7 : 8) : 4)) __attribute__((amdgpu_num_sgpr(80)))
-k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
+template <typename T, bool FULL = false, bool PBC = false, typename OFF = int32_t>
+__global__ void __launch_bounds__(EXPAND_WAVES* WAVE, (sizeof(OFF) == 8 ? 4 : sizeof(T) == 4 ? (FULL ? 7 : 8) : 4)) __attribute__((amdgpu_num_sgpr(80)))
+k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
   constexpr int EW = EXPAND_WAVES;
   constexpr int EXPAND_RMAX = EXPAND_RMAX_OF<FULL>;
@@ -1038,7 +1047,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   const int32_t per_wave = (c.ni + EW - 1) / EW;
   const int32_t r_beg = min(wave * per_wave, c.ni), r_end = min(r_beg + per_wave, c.ni);
   uint32_t w[RB];
-  int32_t base[RB];
+  OFF base[RB];
   auto load_rows = [&](int32_t r0) {
 #pragma unroll
     for (int u = 0; u < RB; u++) {
@@ -1126,8 +1135,6 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
         __builtin_amdgcn_wave_barrier();
         continue;
       }
-#pragma unroll
-      for (int q = 0; q < 4; q++) ptr[q] += (uint32_t)base[u0 + q];
       while (word[0] | word[1] | word[2] | word[3]) {  // a very long row: straight to memory
         int32_t val[4];
         bool on[4];
@@ -1140,7 +1147,7 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           if (on[q]) {
-            *reinterpret_cast<int32_t*>(reinterpret_cast<char*>(a.list) + ((size_t)ptr[q] << 2)) = val[q];
+            a.list[(size_t)base[u0 + q] + ptr[q]] = val[q];
             ptr[q]++;
             word[q] &= word[q] - 1;
           }
@@ -1150,7 +1157,18 @@ k_fill_masks(SweepArgs<T> a, const int32_t* __restrict__ base_sorted) {
   }
 }
 
-}  // namespace nl
+// base_sorted[slot] = key_pointer[sorted_row[slot]]: the list offset of every row, in cell order, so that the placement
+// pass needs one (prefetchable) load per i-particle instead of two dependent ones.
+template <typename OFF>
+__global__ void __launch_bounds__(256) k_row_base(const OFF* __restrict__ key_pointer,
+                                                   const int32_t* __restrict__ sorted_row, int32_t n_rows, int32_t n,
+                                                   OFF* __restrict__ base_sorted) {
+  const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int32_t r = sorted_row[s];
+  // ghosts (slab builds) have no row; in a build that failed its checks a slot may never have been written: unsigned
+  // compare, so that whatever it holds is not used as an index
+  base_sorted[s] = (uint32_t)r < (uint32_t)n_rows ? key_pointer[r] : (OFF)0;
+}
 
-#include "nl_sweep_p.hpp"
-#include "nl_sweep_mfma.hpp"
+}  // namespace nl

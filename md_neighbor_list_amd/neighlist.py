@@ -36,7 +36,7 @@ def _as_tensor(ptr, shape, typestr, owner, device):
     for s in shape:
         n *= int(s)
     if n == 0 or not ptr:
-        dt = {"<i4": torch.int32, "<f4": torch.float32, "<f8": torch.float64}[typestr]
+        dt = {"<i4": torch.int32, "<i8": torch.int64, "<f4": torch.float32, "<f8": torch.float64}[typestr]
         return torch.empty(tuple(int(s) for s in shape), dtype=dt, device=device)
     return torch.as_tensor(_DevView(ptr, shape, typestr, owner), device=device)
 
@@ -94,6 +94,11 @@ class NeighListGPU:
 
     def set_capacity(self, max_pairs):
         check(self._lib.nl_set_capacity(self._h, int(max_pairs)), "nl_set_capacity")
+
+    def set_offset_width(self, bits=0):
+        """Width of the list offsets (nl_set_offset_width): 0 = 64-bit as soon as the list capacity exceeds INT32_MAX
+        entries, 32 / 64 = forced.  The reference's int32 offsets wrap beyond 2^31 pairs (neighlist_cpu.hpp:15,29)."""
+        check(self._lib.nl_set_offset_width(self._h, int(bits)), "nl_set_offset_width")
 
     def set_graph(self, on: bool = True):
         """Replay asynchronous builds from a captured hipGraph (nl_set_graph): saves launch overhead on small systems."""
@@ -206,21 +211,23 @@ class NeighListGPU:
         return 2 * self.half_number_of_pairs()
 
     # ------------------------------------------------------------------ CPU-class surface (half CSR)
-    def _half(self):
+    def _half(self, width=32):
+        """(key_pointer, sorted_list, counts, npairs) pointers; width = 32 | 64 (key_pointer type) | 0 (no key_pointer)."""
         kp, sl, nop, npairs = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
-        check(self._lib.nl_get_half_csr(self._h, C.byref(kp), C.byref(sl), C.byref(nop), C.byref(npairs)),
-              "nl_get_half_csr")
+        f = self._lib.nl_get_half_csr if width == 32 else self._lib.nl_get_half_csr64
+        check(f(self._h, C.byref(kp) if width else None, C.byref(sl), C.byref(nop), C.byref(npairs)), "nl_get_half_csr")
         return kp.value, sl.value, nop.value, int(npairs.value)
 
-    def _full(self):
+    def _full(self, width=32):
         kp, sl, nop, ne = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
-        check(self._lib.nl_get_full_csr(self._h, C.byref(kp), C.byref(sl), C.byref(nop), C.byref(ne)), "nl_get_full_csr")
+        f = self._lib.nl_get_full_csr if width == 32 else self._lib.nl_get_full_csr64
+        check(f(self._h, C.byref(kp) if width else None, C.byref(sl), C.byref(nop), C.byref(ne)), "nl_get_full_csr")
         return kp.value, sl.value, nop.value, int(ne.value)
 
-    def full_csr(self):
+    def full_csr(self, width=32):
         """(key_pointer[N+1], list[2P], counts[N]) of a full-list build, as views valid until the next build."""
-        kp, sl, nop, ne = self._full()
-        return (_as_tensor(kp, (self._n_rows + 1,), "<i4", self, self.device),
+        kp, sl, nop, ne = self._full(width)
+        return (_as_tensor(kp, (self._n_rows + 1,), "<i4" if width == 32 else "<i8", self, self.device),
                 _as_tensor(sl, (ne,), "<i4", self, self.device),
                 _as_tensor(nop, (self._n_rows,), "<i4", self, self.device))
 
@@ -231,19 +238,32 @@ class NeighListGPU:
         return int(npairs.value)
 
     def key_pointer(self):
-        """neighlist_cpu.hpp:449-455 (view, valid until the next build)."""
+        """neighlist_cpu.hpp:449-455 (view, valid until the next build).  int32 like the reference's: raises
+        NL_ERR_INDEX_OVERFLOW for a list of more than INT32_MAX entries (use key_pointer64)."""
         kp, _, _, _ = self._half()
         return _as_tensor(kp, (self._n_rows + 1,), "<i4", self, self.device)
 
+    def key_pointer64(self):
+        """The same offsets as int64 (nl_get_half_csr64): for lists beyond the reference's int32 limit."""
+        kp, _, _, _ = self._half(64)
+        return _as_tensor(kp, (self._n_rows + 1,), "<i8", self, self.device)
+
     def sorted_list(self):
         """neighlist_cpu.hpp:441-447 (view, valid until the next build)."""
-        _, sl, _, npairs = self._half()
+        _, sl, _, npairs = self._half(0 if npairs_exceeds_int32(self) else 32)
         return _as_tensor(sl, (npairs,), "<i4", self, self.device)
 
     def half_number_of_partners(self):
         """neighlist_cpu.hpp:457-463 (view, valid until the next build)."""
-        _, _, nop, _ = self._half()
+        _, _, nop, _ = self._half(0 if npairs_exceeds_int32(self) else 32)
         return _as_tensor(nop, (self._n_rows,), "<i4", self, self.device)
+
+    def list_checksum(self):
+        """Order-independent checksum of the last list, computed on the device (nl_list_checksum): the pair-set hash of
+        the known answers.  Returns (checksum, entries)."""
+        cs, ne = C.c_uint64(), C.c_int64()
+        check(self._lib.nl_list_checksum(self._h, C.byref(cs), C.byref(ne)), "nl_list_checksum")
+        return int(cs.value), int(ne.value)
 
     # ------------------------------------------------------------------ a consumer of the list
     def lj_forces(self, q, epsilon=1.0, sigma=1.0, rc_force=None):
@@ -279,17 +299,25 @@ class NeighListGPU:
 
 
     def build_info(self):
-        """{'masks': bool, 'mfma': bool, 'variant': int, 'lds_batch': int, 'cus': int} of the last build
-        (masks: the list was expanded from hit masks; mfma: those came from the matrix-core search)."""
-        info = (C.c_int32 * 4)()
+        """{'masks': bool, 'variant': int, 'lds_batch': int, 'cus': int, 'offset_bits': 32 | 64} of the last build
+        (masks: the list was expanded from hit masks)."""
+        info = (C.c_int32 * 8)()
         check(self._lib.nl_get_build_info(self._h, C.byref(info)), "nl_get_build_info")
-        return {"masks": bool(info[0]), "mfma": int(info[0]) == 2, "variant": int(info[1]), "lds_batch": int(info[2]), "cus": int(info[3])}
+        return {"masks": bool(info[0]), "variant": int(info[1]), "lds_batch": int(info[2]), "cus": int(info[3]),
+                "offset_bits": int(info[4])}
 
     def profile_last_build(self, reps=10):
         """Same for the last build (also a slab build); its position/id tensors are kept alive by this object."""
         ms = (C.c_double * _lib.NL_NUM_STAGES)()
         check(self._lib.nl_profile_last_build(self._h, int(reps), C.byref(ms)), "nl_profile_last_build")
         return dict(zip(_lib.STAGE_NAMES, (float(v) for v in ms)))
+
+
+def npairs_exceeds_int32(nl) -> bool:
+    """True when the last list is too long for int32 offsets (then the int32 key_pointer accessor is not asked for)."""
+    n = C.c_int64()
+    check(nl._lib.nl_number_of_pairs(nl._h, C.byref(n)), "nl_number_of_pairs")
+    return (2 if nl.full_list else 1) * int(n.value) > 2147483647
 
 
 def device_count() -> int:

@@ -136,8 +136,56 @@ def big(only=None):
         json.dump(out, f, indent=1, sort_keys=True)
 
 
+def big_count(only=None):
+    """Known answers for the boxes beyond the reference's own limits, from the restatement's count / hash mode
+    (oracle/nl_oracle_impl.h nl_oracle_count; pinned to the compiled reference on the 1 M boxes by
+    tests/test_oracle.py): BASELINE config 4 (33 554 432 particles, 2.5e9 pairs > INT32_MAX) with the per-slab
+    answers of the 2-, 4- and 8-way z-slab decompositions, and config 5 (1 M particles, fp64, rc = 6.6)."""
+    import json
+
+    from md_neighbor_list_amd import slab
+
+    path = os.path.join(OUT, "known_answers.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    for name, gen, rc, worlds in (
+        ("u32M_rho1_f32", lambda: inputs.uniform_box(1 << 25, 1.0, np.float32), 3.3, (2, 4, 8)),  # BASELINE config 4
+        ("u16M_rho1_f32", lambda: inputs.uniform_box(1 << 24, 1.0, np.float32), 3.3, ()),  # 1.2e9 pairs: in [2^30, 2^31)
+        ("u1M_rho1_f64_rc66", lambda: inputs.uniform_box(1 << 20, 1.0, np.float64), 6.6, ()),    # BASELINE config 5
+        ("u1M_rho1_f32_rc66", lambda: inputs.uniform_box(1 << 20, 1.0, np.float32), 6.6, ()),
+    ):
+        if only and name not in only:
+            continue
+        q, box = gen()
+        nop, _, hashes, npairs = po.count(q, rc, box)
+        nop64 = nop.astype(np.int64)
+        w = np.arange(len(nop64)) % 1000003
+        out[name] = {"n": int(len(q)), "rc": rc, "box": list(box), "npairs": npairs, "hash": f"{int(hashes[0]):016x}",
+                     "nop_max": int(nop64.max()), "nop_weighted_sum": int((nop64 * w).sum()),
+                     "source": "restatement, count/hash mode"}
+        mz = int(box[2] / rc)
+        cells, _ = po.cells(q, rc, box)
+        layer_of = cells // (int(box[0] / rc) * int(box[1] / rc))
+        for world in worlds:
+            sol = np.zeros(mz, dtype=np.int32)
+            for r, (lo, hi) in enumerate(slab.split_layers(mz, world)):
+                sol[lo:hi] = r
+            _, pairs, hs, np2 = po.count(q, rc, box, sol)
+            assert np2 == npairs
+            owner = sol[layer_of]
+            out[name][f"slabs{world}"] = [
+                {"z_lo": lo, "z_hi": hi, "n_rows": int((owner == r).sum()), "npairs": int(pairs[r]), "hash": f"{int(hs[r]):016x}",
+                 "nop_weighted_sum": int((nop64 * w)[owner == r].sum())}
+                for r, (lo, hi) in enumerate(slab.split_layers(mz, world))]
+        print(name, {k: v for k, v in out[name].items() if not k.startswith("slabs")}, flush=True)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    if "--big" in sys.argv:  # optionally: --big name,name  (only those entries, merged into the stored file)
+    if "--big-count" in sys.argv:
+        k = sys.argv.index("--big-count")
+        big_count(set(sys.argv[k + 1].split(",")) if len(sys.argv) > k + 1 else None)
+    elif "--big" in sys.argv:  # optionally: --big name,name  (only those entries, merged into the stored file)
         k = sys.argv.index("--big")
         big(set(sys.argv[k + 1].split(",")) if len(sys.argv) > k + 1 else None)
     else:

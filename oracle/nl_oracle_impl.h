@@ -395,3 +395,106 @@ int SUF(nl_oracle_build_pbc_full)(const REAL* q, int32_t stride, int64_t N, doub
                                   int64_t* npairs) {
   return SUF(build_pbc_impl)(q, stride, N, rc, Lx, Ly, Lz, number_of_partners, key_pointer, sorted_list, npairs, 1);
 }
+
+/*
+ * Count / hash mode of the same build, for boxes whose list is too large to store or beyond the reference's own
+ * int32 limits (BASELINE config 4: 2.5e9 pairs > INT32_MAX, neighlist_cpu.hpp:15,29; config 5: 2 x rc overruns
+ * MAX_PARTNERS*N, :37,76-78).  Same cells (GenHash :42-59, ApplyPBC :61-66), same 13 + own cell visit
+ * (MakeNeighMeshId :107-132, MakePairListNaive :239-270), same accept rule (:215-223), same owner rule
+ * (pair stored on min(i,j), :225-236) -- but nothing is stored except number_of_partners[] and, per slab of z cell
+ * layers, the pair count and the order-independent pair-set hash of nl_oracle_hash (rows of a slab = particles whose
+ * cell layer belongs to it).  Particles are first copied into cell order (values unchanged), and cells are walked by
+ * OpenMP threads; sums are order independent.
+ *   slab_of_layer[mz] (or NULL = one slab): slab index of every z cell layer; nslab <= 64.
+ */
+int SUF(nl_oracle_count)(const REAL* q, int32_t stride, int64_t N, double rc, double Lx, double Ly, double Lz,
+                         int32_t* number_of_partners, int32_t nslab, const int32_t* slab_of_layer,
+                         uint64_t* hash_per_slab, int64_t* pairs_per_slab, int64_t* npairs) {
+  SUF(grid) g;
+  if (N < 0 || N > 2147483647LL || stride < 3 || nslab < 1 || nslab > 64) return NLO_ERR_ARG;
+  int rc_ = SUF(grid_init)(&g, rc, Lx, Ly, Lz);
+  if (rc_) return rc_;
+  const int64_t M = g.ncell;
+  int32_t* cell_of = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  int64_t* cell_beg = (int64_t*)calloc((size_t)(M + 2), sizeof(int64_t));
+  REAL* qs = (REAL*)malloc(sizeof(REAL) * 3 * (size_t)(N > 0 ? N : 1));
+  int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)(N > 0 ? N : 1));
+  int ret = NLO_OK;
+  if (!cell_of || !cell_beg || !qs || !ids) {
+    ret = NLO_ERR_NOMEM;
+    goto done;
+  }
+  for (int64_t i = 0; i < N; i++) { /* MakeMeshidOfPtcl :134-144 */
+    const int64_t h = SUF(hash_pos)(&g, q + (size_t)i * stride);
+    if (h < 0) {
+      ret = NLO_ERR_OUT_OF_BOX;
+      goto done;
+    }
+    cell_of[i] = (int32_t)h;
+    cell_beg[h + 2]++;
+  }
+  for (int64_t c = 0; c < M; c++) cell_beg[c + 2] += cell_beg[c + 1];
+  for (int64_t i = 0; i < N; i++) { /* MakeNextDest :146-165 (stable), positions carried along */
+    const int64_t s = cell_beg[cell_of[i] + 1]++;
+    ids[s] = (int32_t)i;
+    qs[3 * s] = q[(size_t)i * stride], qs[3 * s + 1] = q[(size_t)i * stride + 1], qs[3 * s + 2] = q[(size_t)i * stride + 2];
+  }
+  memset(number_of_partners, 0, sizeof(int32_t) * (size_t)N);
+  for (int s = 0; s < nslab; s++) hash_per_slab[s] = 0, pairs_per_slab[s] = 0;
+  const int64_t layer = (int64_t)g.m[0] * g.m[1];
+#pragma omp parallel
+  {
+    uint64_t h_loc[64];
+    int64_t p_loc[64];
+    for (int s = 0; s < 64; s++) h_loc[s] = 0, p_loc[s] = 0;
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t c = 0; c < M; c++) {
+      const int32_t iz = (int32_t)(c / layer), iy = (int32_t)((c % layer) / g.m[0]), ix = (int32_t)(c % g.m[0]);
+      int32_t neigh[13];
+      int k = 0;
+      for (int32_t jz = -1; jz < 2 && k < 13; jz++) /* MakeNeighMeshId :107-132 */
+        for (int32_t jy = -1; jy < 2 && k < 13; jy++)
+          for (int32_t jx = -1; jx < 2 && k < 13; jx++) {
+            int32_t idx[3] = {ix + jx, iy + jy, iz + jz};
+            SUF(apply_pbc)(&g, idx);
+            neigh[k++] = (int32_t)SUF(hash_idx)(&g, idx);
+          }
+      const int64_t ib = cell_beg[c], ie = cell_beg[c + 1];
+      for (int64_t a = ib; a < ie; a++) {
+        const int32_t pi = ids[a];
+        const REAL* qi = qs + 3 * a;
+        for (k = 0; k <= 13; k++) {
+          int64_t jb, je;
+          if (k < 13) jb = cell_beg[neigh[k]], je = cell_beg[neigh[k] + 1];
+          else jb = a + 1, je = ie;
+          for (int64_t b = jb; b < je; b++) {
+            if (!SUF(accept)(qi, qs + 3 * b, g.rc2)) continue;
+            const int32_t pj = ids[b];
+            const int32_t lo = pi < pj ? pi : pj, hi = pi < pj ? pj : pi; /* :225-232 */
+#pragma omp atomic
+            number_of_partners[lo]++;
+            const int sl = slab_of_layer ? slab_of_layer[cell_of[lo] / layer] : 0;
+            uint64_t v = ((uint64_t)(uint32_t)lo << 32) | (uint32_t)hi;
+            v *= 0x9E3779B97F4A7C15ULL;
+            v ^= v >> 29;
+            h_loc[sl] += v;
+            p_loc[sl]++;
+          }
+        }
+      }
+    }
+#pragma omp critical
+    for (int s = 0; s < nslab; s++) hash_per_slab[s] += h_loc[s], pairs_per_slab[s] += p_loc[s];
+  }
+  {
+    int64_t P = 0;
+    for (int s = 0; s < nslab; s++) P += pairs_per_slab[s];
+    *npairs = P;
+  }
+done:
+  free(cell_of);
+  free(cell_beg);
+  free(qs);
+  free(ids);
+  return ret;
+}

@@ -86,6 +86,10 @@ def _lib():
             f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_int,
                           C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+            f = getattr(lib, "nl_oracle_count_" + s)
+            f.restype = C.c_int
+            f.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                          C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
             f = getattr(lib, "nl_oracle_cells_" + s)
             f.restype = C.c_int
             f.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -121,6 +125,29 @@ def build(q, rc, box) -> HalfList:
     if rc_:
         raise OracleError(rc_)
     return HalfList(nop, kp, _take(ptr, npairs.value))
+
+
+def count(q, rc, box, slab_of_layer=None):
+    """Count / hash mode of the restated build (nl_oracle_count): nothing is stored but number_of_partners, and per
+    slab of z cell layers the pair count and the pair-set hash of the rows it owns.  For boxes beyond the reference's
+    own limits (BASELINE configs 4 and 5).  Returns (number_of_partners[N], pairs_per_slab, hash_per_slab, npairs)."""
+    q, s = _prep(q)
+    n = q.shape[0]
+    nop = np.zeros(n, dtype=np.int32)
+    if slab_of_layer is None:
+        nslab, sol_ptr = 1, None
+    else:
+        sol = np.ascontiguousarray(slab_of_layer, dtype=np.int32)
+        nslab, sol_ptr = int(sol.max()) + 1, sol.ctypes.data
+    hashes = np.zeros(nslab, dtype=np.uint64)
+    pairs = np.zeros(nslab, dtype=np.int64)
+    npairs = C.c_int64()
+    rc_ = getattr(_lib(), "nl_oracle_count_" + s)(q.ctypes.data, q.shape[1], n, rc, box[0], box[1], box[2],
+                                                  nop.ctypes.data, nslab, sol_ptr, hashes.ctypes.data, pairs.ctypes.data,
+                                                  C.byref(npairs))
+    if rc_:
+        raise OracleError(rc_)
+    return nop, pairs, hashes, int(npairs.value)
 
 
 def build_pbc(q, rc, box) -> HalfList:

@@ -15,6 +15,8 @@ from tests.util import GOLDEN, canonical_csr, golden_names, gpu_build, load_gold
 
 pytestmark = pytest.mark.gpu
 
+SWEEP_VARIANTS = [1, 3]  # NL_SWEEP_VARIANT values the library accepts (3 = default)
+
 
 def _po():
     from oracle import pyoracle as po
@@ -209,10 +211,10 @@ def test_baseline_sizes_known_answers(key):
         assert np.array_equal(np.sort(sl[kp[i]:kp[i + 1]]), want.astype(np.int32))
 
 
-@pytest.mark.parametrize("variant,binning", [(1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (4, 1), (1, 1)])
+@pytest.mark.parametrize("variant,binning", [(v, b) for v in SWEEP_VARIANTS for b in (0, 1)])
 def test_every_sweep_variant_and_binning_path(variant, binning, monkeypatch):
-    """The non-default kernels stay correct: NL_SWEEP_VARIANT 1 (COUNT + FILL sweeps), 2 (persistent LDS-DMA),
-    3 (VALU hit masks, default), 4 / 5 (matrix-core hit masks, fp32 / f16 two-piece); NL_BINNING=1 (atomic-rank hash/reorder)."""
+    """The non-default kernels stay correct: NL_SWEEP_VARIANT 1 (COUNT + FILL sweeps), 3 (27-cell hit masks);
+    NL_BINNING=1 (atomic-rank hash/reorder)."""
     monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
     monkeypatch.setenv("NL_BINNING", str(binning))
     for n, box, rc, seed in [(50000, (36.84, 36.84, 36.84), 3.3, 41), (9000, (25.0, 14.0, 19.0), 3.1, 42)]:
@@ -225,11 +227,10 @@ def test_every_sweep_variant_and_binning_path(variant, binning, monkeypatch):
         assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5])
+@pytest.mark.parametrize("variant", SWEEP_VARIANTS)
 def test_pairs_at_the_cutoff_fp32(variant, monkeypatch):
-    """Partners placed at distance rc*(1 +- k ulp) around random centres: every one of them falls inside the band
-    that the matrix-core searches (k_sweep_mfma_f32 / _f16, variants 4 / 5) must re-test with the reference's exact fp32
-    expression; variant 3 tests them with that expression directly."""
+    """Partners placed at distance rc*(1 +- k ulp) around random centres: the cut-off decision must be the reference's
+    exact fp32 expression (separately rounded products and sums, compared against the double rc*rc)."""
     monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
     rng = np.random.default_rng(77)
     rc, L = 3.3, 40.0
@@ -364,10 +365,10 @@ def test_random_small_boxes_against_oracle():
             assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), case
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5])
+@pytest.mark.parametrize("variant", [v for v in SWEEP_VARIANTS if v >= 3])
 def test_random_mask_pipeline_boxes_against_oracle(variant, monkeypatch):
-    """Twelve seeded random problems large enough for the hit-mask pipelines (VALU masks, matrix-core masks):
-    non-cubic boxes of 5..10 cells per axis with 15..38 particles per cell."""
+    """Twelve seeded random problems large enough for the hit-mask pipelines: non-cubic boxes of 5..10 cells per axis
+    with 15..38 particles per cell."""
     monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
     rng = np.random.default_rng(99 + variant)
     for case in range(12):
@@ -379,7 +380,7 @@ def test_random_mask_pipeline_boxes_against_oracle(variant, monkeypatch):
         ref = _po().build(q, rc, box)
         nl, nop, kp, sl = gpu_build(q, rc, box)
         info = nl.build_info()
-        assert info["masks"] and info["mfma"] == (variant >= 4), (case, info)
+        assert info["masks"] and info["variant"] == variant, (case, info)
         assert int(kp[-1]) == ref.npairs, case
         assert np.array_equal(nop, ref.number_of_partners), case
         assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), case
@@ -387,9 +388,12 @@ def test_random_mask_pipeline_boxes_against_oracle(variant, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("full", [False, True])
-def test_lj_forces_from_the_list(dtype, full):
+@pytest.mark.parametrize("pbc", [False, True])
+def test_lj_forces_from_the_list(dtype, full, pbc):
     """The list's consumer: Lennard-Jones forces and energies from the half list (atomics) and
-    from the full list (gather) against float64 numpy on the oracle's pair list."""
+    from the full list (gather) against float64 numpy on the oracle's pair list; tolerance 2e-4 (fp32) / 1e-11 (fp64)
+    of the largest component.  pbc: the minimum-image list -- pairs across the periodic faces must enter the forces
+    at their image (the consumer used raw coordinates and dropped them silently)."""
     import torch
 
     from md_neighbor_list_amd import NeighListGPU
@@ -397,10 +401,14 @@ def test_lj_forces_from_the_list(dtype, full):
     n, box, rc = 30000, (32.0, 32.0, 32.0), 3.0
     q, box = inputs.uniform_box(n, dtype=dtype, seed=61, box=box)
     # keep particles apart (r > 0.8 sigma) so that the reference sum is well conditioned in fp32
-    ref = _po().build(q, rc, box)
+    ref = _po().build_pbc(q, rc, box) if pbc else _po().build(q, rc, box)
     rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ref.key_pointer))
     cols = ref.sorted_list.astype(np.int64)
     d = q[rows, :3].astype(np.float64) - q[cols, :3].astype(np.float64)
+    if pbc:
+        L = np.array(box, dtype=np.float64)
+        d -= L * np.round(d / L)
+        assert np.any(np.abs(q[rows, :3].astype(np.float64) - q[cols, :3].astype(np.float64)).max(axis=1) > 16.0)
     r2 = (d * d).sum(axis=1)
     keep = r2 > 0.64
     rows, cols, d, r2 = rows[keep], cols[keep], d[keep], r2[keep]
@@ -418,7 +426,8 @@ def test_lj_forces_from_the_list(dtype, full):
     close[rr[~keep]] = True
     close[ref.sorted_list.astype(np.int64)[~keep]] = True
 
-    nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64, full_list=full)
+    nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64, full_list=full,
+                      minimum_image=pbc)
     nl.Initialize(n)
     qd = torch.from_numpy(q).cuda()
     nl.MakeNeighList(qd, n)
@@ -550,55 +559,11 @@ def test_minimum_image_full_list_is_evaluated_in_the_row_frame():
         assert np.array_equal(canonical_csr(kp, lst), want.sorted_list)
 
 
-def test_full_list_from_the_matrix_core_search(monkeypatch):
-    """NL_SWEEP_VARIANT=5 with NL_LIST_FULL: the f16 matrix-core search in its full-list form (no id test per pair, the
-    row's own bit cleared at the end) -- random boxes incl. particles on the box edge (VALU fall-back cells), and
-    partners at rc*(1 +- k ulp) (every one inside the band that is re-tested exactly)."""
-    import torch
-
-    from md_neighbor_list_amd import NeighListGPU
-
-    monkeypatch.setenv("NL_SWEEP_VARIANT", "5")
-    rng = np.random.default_rng(55)
-    cases = []
-    for k in range(6):
-        rc = float(rng.uniform(1.5, 4.0))
-        mesh = rng.integers(4, 12, size=3)
-        box = tuple(float(m * rc * rng.uniform(1.0, 1.25)) for m in mesh)
-        n = int(int(mesh[0]) * int(mesh[1]) * int(mesh[2]) * rng.uniform(15.0, 40.0))
-        q = np.zeros((n, 4), dtype=np.float32)
-        q[:, :3] = rng.uniform(0.0, 1.0, size=(n, 3)) * np.array(box)
-        q[:40, :3] = np.round(q[:40, :3] / np.array(box)) * np.array(box)  # on the faces
-        q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=np.float32), np.float32(0)))
-        cases.append((q, rc, box))
-    rc, L, nc = 3.3, 40.0, 6000
-    centres = rng.uniform(4.0, L - 4.0, size=(nc, 3))
-    d = rng.normal(size=(nc, 3))
-    d /= np.linalg.norm(d, axis=1, keepdims=True)
-    scale = 1.0 + rng.integers(-6, 7, size=(nc, 1)) * 2.0 ** -23
-    q = np.zeros((2 * nc, 4), dtype=np.float32)
-    q[:, :3] = np.concatenate([centres, centres + d * rc * scale]).astype(np.float32)
-    cases.append((q[rng.permutation(len(q))], rc, (L, L, L)))
-    used = 0
-    for q, rc, box in cases:
-        n = len(q)
-        want_kp, want_list, want_cnt = _full_from_half(_po().build(q, rc, box))
-        nl = NeighListGPU(rc, *box, dtype=torch.float32, full_list=True)
-        nl.Initialize(n)
-        nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
-        used += int(nl.build_info()["mfma"])
-        kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr())
-        assert np.array_equal(cnt, want_cnt)
-        assert np.array_equal(kp.astype(np.int64), want_kp)
-        assert np.array_equal(canonical_csr(kp, lst), want_list)
-    assert used >= 4, "the matrix-core kernel must have been the one running"
-
-
-@pytest.mark.parametrize("variant", [3, 5])
+@pytest.mark.parametrize("variant", [v for v in SWEEP_VARIANTS if v >= 3])
 def test_full_list_at_baseline_size(variant, monkeypatch):
-    """BASELINE config 2 (N = 1 048 576) as a FULL list -- the VALU search without the id test (own bit cleared at the
-    end) and the opt-in matrix-core form: twice the stored pair count, every row symmetric on a sample, and the upper
-    part (j > i) of the list hashes to the stored answer of the half list."""
+    """BASELINE config 2 (N = 1 048 576) as a FULL list -- the search without the id test (own bit cleared at the
+    end): twice the stored pair count, every row symmetric on a sample, and the upper part (j > i) of the list hashes
+    to the stored answer of the half list."""
     import torch
 
     from md_neighbor_list_amd import NeighListGPU
@@ -611,7 +576,7 @@ def test_full_list_at_baseline_size(variant, monkeypatch):
     nl = NeighListGPU(ka["rc"], *box, dtype=torch.float32, full_list=True)
     nl.Initialize(n)
     nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
-    assert bool(nl.build_info()["mfma"]) == (variant == 5)
+    assert nl.build_info()["variant"] == variant
     kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr())
     assert int(kp[-1]) == 2 * ka["npairs"] == len(lst)
     assert np.array_equal(np.diff(kp), cnt)
@@ -705,3 +670,209 @@ def test_weak_scaling_boxes_on_one_gpu(key):
     assert int((nop * (np.arange(len(nop)) % 1000003)).sum()) == ka["nop_weighted_sum"]
     kp = nl.key_pointer().cpu().numpy()
     assert int(kp[-1]) == ka["npairs"] and np.array_equal(np.diff(kp), nop)
+
+
+# ---------------------------------------------------------------------------------------------- 64-bit list offsets
+@pytest.mark.parametrize("variant", SWEEP_VARIANTS)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wide_offsets_give_the_same_lists(variant, dtype, monkeypatch):
+    """nl_set_offset_width(64): the build keeps int64 list offsets (what a list beyond INT32_MAX entries needs, e.g.
+    BASELINE config 4 on one device) -- on boxes the oracle finishes in seconds the lists must be the reference's, the
+    int64 key_pointer its prefix sums, and the int32 accessor a faithful conversion.  Half and full list."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
+    for n, box, rc, seed in [(40000, (34.2, 34.2, 34.2), 3.3, 5), (4096, (16.0, 16.0, 16.0), 3.3, 6), (30000, (20.0, 20.0, 20.0), 6.0, 7)]:
+        q, box = inputs.uniform_box(n, dtype=dtype, seed=seed, box=box)
+        ref = _po().build(q, rc, box)
+        nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64)
+        nl.set_offset_width(64)
+        nl.Initialize(n)
+        qd = torch.from_numpy(q).cuda()
+        nl.MakeNeighList(qd, n)
+        assert nl.build_info()["offset_bits"] == 64
+        kp64 = nl.key_pointer64().cpu().numpy()
+        assert kp64.dtype == np.int64 and np.array_equal(kp64, ref.key_pointer)
+        kp32 = nl.key_pointer().cpu().numpy()
+        assert kp32.dtype == np.int32 and np.array_equal(kp32.astype(np.int64), kp64)
+        sl = nl.sorted_list().cpu().numpy()
+        assert np.array_equal(canonical_csr(kp64, sl), ref.canonical().sorted_list)
+        cs, ne = nl.list_checksum()
+        assert ne == ref.npairs and cs == ref.hash()
+        f = nl.lj_forces(qd)  # the consumer reads the int64 offsets
+        nl.set_offset_width(32)
+        nl.MakeNeighList(qd, n)
+        assert nl.build_info()["offset_bits"] == 32
+        assert np.array_equal(nl.key_pointer64().cpu().numpy(), ref.key_pointer)
+        assert torch.allclose(f, nl.lj_forces(qd), rtol=1e-4, atol=1e-4)
+        # full list
+        nl.set_offset_width(64)
+        nl.set_full_list(True)
+        nl.MakeNeighList(qd, n)
+        want_kp, want_list, want_cnt = _full_from_half(ref)
+        kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr(64))
+        assert np.array_equal(kp, want_kp) and np.array_equal(cnt, want_cnt)
+        assert np.array_equal(canonical_csr(kp, lst), want_list)
+
+
+def test_wide_offsets_by_capacity_and_overflow_status():
+    """The width follows the capacity: a handle whose list may hold more than INT32_MAX entries builds with int64
+    offsets; nl_set_offset_width(32) on a list that needs more is an error status, never a wrapped list."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+    from md_neighbor_list_amd._lib import NL_ERR_INDEX_OVERFLOW, NLError
+
+    q, box = inputs.uniform_box(36000, dtype=np.float32, seed=7, box=(34.2, 34.2, 34.2))
+    ref = _po().build(q, 3.3, box)
+    nl = NeighListGPU(3.3, *box, dtype=torch.float32)
+    nl.Initialize(len(q))
+    nl.set_capacity((1 << 31) + 4096)  # 8 GiB of list: fits a 288 GB device many times over
+    nl.MakeNeighList(torch.from_numpy(q).cuda(), len(q))
+    assert nl.build_info()["offset_bits"] == 64
+    assert nl.half_number_of_pairs() == ref.npairs
+    assert np.array_equal(canonical_csr(nl.key_pointer64().cpu().numpy(), nl.sorted_list().cpu().numpy()),
+                          ref.canonical().sorted_list)
+
+
+def test_list_between_2_30_and_2_31_entries():
+    """A list of 1.2e9 entries (16 M particles, rho = 1) with 32-bit offsets: beyond 2^30 entries a 32-bit BYTE offset
+    wraps -- every list address is formed in 64 bits.  Pair count, number_of_partners checksum and the device-side
+    pair-set checksum against the restatement's count-mode answer; both pipelines (masks, two sweeps)."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))["u16M_rho1_f32"]
+    q, box = inputs.uniform_box(ka["n"], 1.0, np.float32)
+    qd = torch.from_numpy(q).cuda()
+    for variant in SWEEP_VARIANTS:
+        os.environ["NL_SWEEP_VARIANT"] = str(variant)
+        try:
+            nl = NeighListGPU(ka["rc"], *box, dtype=torch.float32)
+        finally:
+            del os.environ["NL_SWEEP_VARIANT"]
+        nl.set_offset_width(32)
+        nl.Initialize(len(q))
+        nl.MakeNeighList(qd, len(q))
+        assert nl.build_info()["offset_bits"] == 32 and nl.build_info()["variant"] == variant
+        assert (1 << 30) < nl.half_number_of_pairs() == ka["npairs"] < (1 << 31)
+        nop = nl.half_number_of_partners().cpu().numpy().astype(np.int64)
+        assert int((nop * (np.arange(len(nop)) % 1000003)).sum()) == ka["nop_weighted_sum"]
+        cs, ne = nl.list_checksum()
+        assert ne == ka["npairs"] and f"{cs:016x}" == ka["hash"]
+        del nl
+
+
+def _check_known_answer_on_device(nl, ka):
+    """Pair count, count checksum, maximum and the device-side pair-set checksum of the last build against a stored answer."""
+    assert nl.half_number_of_pairs() == ka["npairs"]
+    nop = nl.half_number_of_partners().cpu().numpy().astype(np.int64)
+    assert int(nop.max()) == ka["nop_max"]
+    assert int((nop * (np.arange(len(nop)) % 1000003)).sum()) == ka["nop_weighted_sum"]
+    cs, ne = nl.list_checksum()
+    assert ne == ka["npairs"] and f"{cs:016x}" == ka["hash"]
+    return nop
+
+
+def test_config4_on_one_gpu():
+    """BASELINE config 4 (N = 33 554 432, rho = 1: 2 496 524 913 pairs > INT32_MAX) on ONE device: 64-bit offsets by
+    capacity, the restatement's count-mode answer (the reference itself overflows here, neighlist_cpu.hpp:15,29)."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+    from md_neighbor_list_amd._lib import NL_ERR_INDEX_OVERFLOW, NLError
+
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))["u32M_rho1_f32"]
+    q, box = inputs.uniform_box(ka["n"], 1.0, np.float32)
+    nl = NeighListGPU(ka["rc"], *box, dtype=torch.float32)
+    nl.Initialize(len(q))
+    qd = torch.from_numpy(q).cuda()
+    nl.MakeNeighList(qd, len(q))
+    assert nl.build_info()["offset_bits"] == 64
+    nop = _check_known_answer_on_device(nl, ka)
+    kp = nl.key_pointer64().cpu().numpy()
+    assert int(kp[-1]) == ka["npairs"] and np.array_equal(np.diff(kp), nop)
+    with pytest.raises(NLError) as e:  # the reference's int32 key_pointer cannot address this list
+        nl.key_pointer()
+    assert e.value.code == NL_ERR_INDEX_OVERFLOW
+    # a few rows against an O(N) scan
+    sl = nl.sorted_list()
+    rng = np.random.default_rng(4)
+    rc2 = ka["rc"] * ka["rc"]
+    for i in rng.integers(0, len(q), size=4):
+        d = q[:, :3] - q[i, :3]
+        r2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        want = np.nonzero(~(r2.astype(np.float64) > rc2) & (np.arange(len(q)) > i))[0]
+        assert np.array_equal(np.sort(sl[kp[i]:kp[i + 1]].cpu().numpy()), want.astype(np.int32))
+
+
+def test_config4_as_eight_slabs_on_one_gpu():
+    """BASELINE config 4 cut into the 8 z-slabs of bench.py --gpus 8, built one after another on ONE device (owned
+    particles + the two ghost layers, exactly what every rank builds): per-slab pair count, count checksum and pair-set
+    checksum against the restatement's per-slab answers; their sum is the global answer."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU, slab
+
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))["u32M_rho1_f32"]
+    q, box = inputs.uniform_box(ka["n"], 1.0, np.float32)
+    rc = ka["rc"]
+    qd = torch.from_numpy(q).cuda()
+    iz = slab.z_layer(qd, box, rc)
+    mz = int(box[2] / rc)
+    gid = torch.arange(len(q), dtype=torch.int32, device="cuda")
+    w = (torch.arange(len(q), dtype=torch.int64, device="cuda") % 1000003)
+    total_pairs, total_cs = 0, 0
+    nl = NeighListGPU(rc, *box, dtype=torch.float32)
+    for r, (z_lo, z_hi) in enumerate(slab.split_layers(mz, 8)):
+        want = ka["slabs8"][r]
+        assert (z_lo, z_hi) == (want["z_lo"], want["z_hi"])
+        own = torch.nonzero((iz >= z_lo) & (iz < z_hi)).flatten()
+        g_lo = torch.nonzero(iz == (z_lo - 1) % mz).flatten()
+        g_hi = torch.nonzero(iz == z_hi % mz).flatten()
+        idx = torch.cat([own, g_lo, g_hi])
+        q_all, gid_all = qd[idx].contiguous(), gid[idx].contiguous()
+        n_rows = int(own.numel())
+        assert n_rows == want["n_rows"]
+        nl.Initialize(int(idx.numel()))
+        nl.set_capacity(int(n_rows * 75 * 1.3) + 4096)
+        nl.MakeNeighListSlab(q_all, gid_all, n_rows, z_lo, z_hi)
+        assert nl.half_number_of_pairs() == want["npairs"]
+        nop = nl.half_number_of_partners().to(torch.int64)
+        assert int((nop * w[own]).sum().item()) == want["nop_weighted_sum"]
+        cs, ne = nl.list_checksum()
+        assert ne == want["npairs"] and f"{cs:016x}" == want["hash"], r
+        total_pairs += ne
+        total_cs = (total_cs + cs) & ((1 << 64) - 1)
+    assert total_pairs == ka["npairs"] and f"{total_cs:016x}" == ka["hash"]
+
+
+@pytest.mark.parametrize("key", ["u1M_rho1_f64_rc66", "u1M_rho1_f32_rc66"])
+def test_config5_full_size(key):
+    """BASELINE config 5 at its stated size: N = 1 048 576, rc = 6.6 (2 x cut-off: 311 particles per cell, 5.9e8
+    pairs), fp64 (and the fp32 sibling).  The reference overruns its MAX_PARTNERS*N buffers there
+    (neighlist_cpu.hpp:37,76-78); the answer is the restatement's count mode."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))[key]
+    dt = np.float64 if "f64" in key else np.float32
+    q, box = inputs.uniform_box(ka["n"], 1.0, dt)
+    nl = NeighListGPU(ka["rc"], *box, dtype=torch.float64 if dt == np.float64 else torch.float32)
+    nl.Initialize(len(q))
+    nl.MakeNeighList(torch.from_numpy(q).cuda(), len(q))
+    nop = _check_known_answer_on_device(nl, ka)
+    kp = nl.key_pointer().cpu().numpy()
+    assert np.array_equal(np.diff(kp), nop)
+    sl = nl.sorted_list()
+    rng = np.random.default_rng(5)
+    rc2 = ka["rc"] * ka["rc"]
+    for i in rng.integers(0, len(q), size=6):
+        d = q[:, :3] - q[i, :3]
+        r2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        want = np.nonzero(~(r2.astype(np.float64) > rc2) & (np.arange(len(q)) > i))[0]
+        assert np.array_equal(np.sort(sl[kp[i]:kp[i + 1]].cpu().numpy()), want.astype(np.int32))

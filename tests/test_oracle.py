@@ -173,3 +173,43 @@ def test_minimum_image_full_oracle_is_the_row_frame_list():
     have = np.zeros((m, m), dtype=bool)
     have[rows, full.sorted_list] = True
     assert (have != have.T).any(), "pairs accepted in one direction only are what this mode's definition is about"
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_count_mode_equals_the_stored_list(dtype):
+    """nl_oracle_count (no pair storage; the source of the config 4 / config 5 known answers) against the list-building
+    restatement on the same box: counts, total, pair-set hash, and the per-slab split of both."""
+    from md_neighbor_list_amd import slab
+
+    q, box = inputs.uniform_box(20000, dtype=dtype, seed=21, box=(23.0, 27.0, 33.5))
+    rc = 3.3
+    ref = po.build(q, rc, box)
+    nop, pairs, hashes, npairs = po.count(q, rc, box)
+    assert npairs == ref.npairs == int(pairs[0]) and int(hashes[0]) == ref.hash()
+    assert np.array_equal(nop, ref.number_of_partners)
+    mz = int(box[2] / rc)
+    sol = np.zeros(mz, dtype=np.int32)
+    for r, (lo, hi) in enumerate(slab.split_layers(mz, 3)):
+        sol[lo:hi] = r
+    nop3, pairs3, hashes3, np3 = po.count(q, rc, box, sol)
+    assert np3 == ref.npairs and np.array_equal(nop3, nop)
+    cells, mesh = po.cells(q, rc, box)
+    owner = sol[cells // (mesh[0] * mesh[1])]
+    for r in range(3):
+        rows = np.nonzero(owner == r)[0]
+        assert int(pairs3[r]) == int(ref.number_of_partners[rows].sum())
+        kp = np.concatenate([[0], np.cumsum(np.where(owner == r, ref.number_of_partners, 0))]).astype(np.int64)
+        lst = np.concatenate([ref.sorted_list[ref.key_pointer[i]:ref.key_pointer[i + 1]] for i in rows] or [np.zeros(0, np.int32)])
+        assert int(hashes3[r]) == po.HalfList(None, kp, lst.astype(np.int32)).hash()
+    assert (int(hashes3.astype(object).sum()) & ((1 << 64) - 1)) == ref.hash()
+
+
+def test_count_mode_reproduces_the_compiled_reference_at_1M():
+    """Pins count mode to the compiled reference at BASELINE size: the stored answer of config 2 (written by
+    gen_golden.py --big from oracle/_ref) is reproduced exactly."""
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))["u1M_rho1_f32"]
+    q, box = inputs.uniform_box(ka["n"], 1.0, np.float32)
+    nop, _, hashes, npairs = po.count(q, ka["rc"], box)
+    assert npairs == ka["npairs"] and f"{int(hashes[0]):016x}" == ka["hash"]
+    nop = nop.astype(np.int64)
+    assert int(nop.max()) == ka["nop_max"] and int((nop * (np.arange(len(nop)) % 1000003)).sum()) == ka["nop_weighted_sum"]
