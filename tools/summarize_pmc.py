@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 CSV output directories (kernel-trace stats and --pmc passes) into per-kernel averages.
 
-usage: tools/summarize_pmc.py <dir> [--json out.json]
-Finds every *counter_collection.csv and *kernel_trace.csv below <dir>.  Counter values are averaged per dispatch
+usage: tools/summarize_pmc.py <dir> [<dir> ...] [--json out.json]
+Finds every *counter_collection.csv and *kernel_trace.csv below the directories.  Counter values are averaged per dispatch
 and per kernel name (template arguments kept).  FETCH_SIZE/WRITE_SIZE are reported in bytes with the gfx950
 corrections of /opt/skills/guides/MI355X_MICROARCH.md (section HBM): the counters are in KiB, and FETCH_SIZE
 reads exactly half of a wide coalesced stream, so 'fetch_bytes_x2' is the figure to compare with a byte count.
@@ -21,10 +21,10 @@ def short(name):
 
 
 def main():
-    root = sys.argv[1]
     out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    roots = [a for a in sys.argv[1:] if a != "--json" and a != out_json]
     counters = defaultdict(lambda: defaultdict(list))
-    for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    for path in [p for r in roots for p in glob.glob(os.path.join(r, "**", "*counter_collection.csv"), recursive=True)]:
         with open(path, newline="") as f:
             rd = csv.DictReader(f)
             per_dispatch = defaultdict(float)
@@ -37,7 +37,7 @@ def main():
             for (k, c, d), v in per_dispatch.items():
                 counters[short(k)][c].append(v)
     durations = defaultdict(list)
-    for path in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
+    for path in [p for r in roots for p in glob.glob(os.path.join(r, "**", "*kernel_trace.csv"), recursive=True)]:
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
                 try:
