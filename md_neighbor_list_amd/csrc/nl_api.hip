@@ -26,6 +26,7 @@ struct HostResult {
   int64_t total() const { return (int64_t)(((uint64_t)total_hi << 32) | total_lo); }
 };
 constexpr int META_TOTAL = 18;  // int32 offset of total_lo from the status word
+constexpr int META_FULL27 = 1;  // number of cells the half-shell path hands to the 27-cell search (first "ticket" word)
 constexpr int META_WORDS = 20;
 
 }  // namespace
@@ -67,6 +68,15 @@ struct nl_handle_s {
   bool bin_two_level = true;      // NL_BINNING=1 selects the atomic-rank path (k_hash/k_reorder)
   void* base_sorted = nullptr;     // key_pointer of every sorted slot (mask expansion), same width as key_pointer
   uint32_t* masks = nullptr;       // [n][64] hit bits of every sorted slot, between COUNT_MASKS and k_fill_masks
+  // half-shell search (nl_half.hpp): F words, R words, their counts
+  uint16_t* fmask = nullptr;
+  unsigned long long* rmask = nullptr;
+  uint32_t* fcnt = nullptr;
+  uint8_t* rcnt = nullptr;
+  int32_t* full27_list = nullptr;
+  int64_t rstride = 0;
+  bool b_half = false;             // this build: half-shell search
+  int half_cpb = 4;                // cells a workgroup of k_sweep_half walks (NL_HALF_CPB)
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps;
                                    // 3 (default): COUNT keeping hit masks + mask expansion
                                    // (2 = persistent LDS-DMA sweeps, 4 / 5 = matrix-core searches: measured slower or a draw
@@ -246,6 +256,9 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.capacity = h->capacity;
   a.status = h->status;
   a.masks = h->masks;
+  a.fmask = h->fmask, a.rmask = h->rmask, a.fcnt = h->fcnt, a.rcnt = h->rcnt, a.rstride = h->rstride;
+  a.full27_list = h->full27_list;
+  a.full27_count = reinterpret_cast<int32_t*>(h->status) + META_FULL27;
   a.pbc = h->pbc ? 1 : 0;
   for (int d = 0; d < 3; d++) a.L[d] = (T)h->L[d];
   a.z_origin = h->b_slab ? h->b_zlo - 1 : 0;
@@ -264,10 +277,40 @@ template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(
                      static_cast<const OFF*>(h->base_sorted));
 }
 
+template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_half(nl_handle_t h, const SweepArgs<T>& a, int32_t ncells_i, hipStream_t s) {
+  const int32_t nbp = (h->n + 255) / 256;
+  if (h->n > 0)
+    hipLaunchKernelGGL(k_row_base<OFF>, dim3(nbp), dim3(256), 0, s, static_cast<const OFF*>(h->key_pointer), h->sorted_row,
+                       h->n_rows, h->n, static_cast<OFF*>(h->base_sorted));
+  SweepArgs<T> ah = a;
+  ah.cells_per_block = h->half_cpb, ah.ncells_grid = ncells_i;
+  hipLaunchKernelGGL((k_fill_half<T, FULL, PBC, OFF>), dim3((ncells_i + h->half_cpb - 1) / h->half_cpb), dim3(HF_WAVES * WAVE), 0, s, ah,
+                     static_cast<const OFF*>(h->base_sorted));
+  hipLaunchKernelGGL((k_full27<T, MODE_FILL, FULL, PBC>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
+}
+
 template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h, int mode, hipStream_t s) {
   const int32_t owned_layers = h->b_slab ? h->b_mzl - 2 : h->b_mzl;
   const int32_t ncells_i = h->m[0] * h->m[1] * owned_layers;
   const SweepArgs<T> a = sweep_args<T>(h);
+  if (h->b_half && mode == MODE_COUNT) {
+    // every local layer but a slab's upper ghost layer sweeps (the lower ghost layer is the lower neighbour of layer 1)
+    const int32_t ncells_h = h->m[0] * h->m[1] * (h->b_slab ? h->b_mzl - 1 : h->b_mzl);
+    SweepArgs<T> ah = a;
+    ah.cells_per_block = h->half_cpb, ah.ncells_grid = ncells_h;
+    hipLaunchKernelGGL((k_sweep_half<T, FULL, PBC>), dim3((ncells_h + h->half_cpb - 1) / h->half_cpb), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
+    ah.ncells_grid = ncells_i;  // cells with an irregular stencil: counted by the 27-cell search
+    hipLaunchKernelGGL((k_full27<T, MODE_COUNT, FULL, PBC>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
+    if (h->n > 0)
+      hipLaunchKernelGGL(k_half_counts, dim3((h->n + 255) / 256), dim3(256), 0, s, h->fcnt, h->rcnt, h->rstride, h->sorted_row,
+                         h->n_rows, h->n, h->count);
+    return;
+  }
+  if (h->b_half && h->b_variant >= 6) {  // (variant 5: half-shell COUNT, rows by a second 27-cell sweep -- diagnostics)
+    if (h->b_wide) launch_fill_half<T, FULL, PBC, int64_t>(h, a, ncells_i, s);
+    else launch_fill_half<T, FULL, PBC, int32_t>(h, a, ncells_i, s);
+    return;
+  }
   if (h->b_use_masks) {
     if (mode == MODE_COUNT) {
       if constexpr (sizeof(T) == 4)
@@ -319,7 +362,9 @@ void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int
   h->b_variant = h->sweep_variant;
   // Hit masks pay off while a cell's stencil fits one LDS batch; where the mean stencil (27 cells) is close to or
   // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
-  h->b_use_masks = h->b_variant >= 3 && h->masks && 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;
+  const bool sparse_enough = 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;  // mean stencil <= 1088: <= 40.3 per cell
+  h->b_half = h->b_variant >= 5 && h->fmask && sparse_enough;
+  h->b_use_masks = h->b_variant >= 3 && h->b_variant < 5 && h->masks && sparse_enough;
   // 64-bit list offsets as soon as the list this handle can hold exceeds what an int32 key_pointer can address
   // (the reference's own limit, neighlist_cpu.hpp:15,29); nl_set_offset_width overrides.
   h->b_wide = h->offset_width == 64 || (h->offset_width == 0 && h->capacity > 2147483647LL);
@@ -650,7 +695,8 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
-    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : 3;
+    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : atoi(v) >= 6 ? 6 : atoi(v) == 5 ? 5 : 3;
+    if (const char* v = getenv("NL_HALF_CPB")) h->half_cpb = std::max(1, atoi(v));
     if (const char* v = getenv("NL_OFFSET_WIDTH")) h->offset_width = atoi(v) == 64 ? 64 : atoi(v) == 32 ? 32 : 0;
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_GRAPH")) h->use_graph = atoi(v) != 0;
@@ -666,7 +712,7 @@ int nl_destroy(nl_handle_t h) {
   if (!h) return NL_ERR_ARG;
   (void)hipSetDevice(h->device);
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
-  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->kp_alt, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->dbg_buf, h->cell_count,
+  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->kp_alt, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->fmask, h->rmask, h->fcnt, h->rcnt, h->full27_list, h->dbg_buf, h->cell_count,
                   h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -714,7 +760,15 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
     if ((rc = dev_alloc(h, &h->tmp_pos, pos_bytes * (n + 16)))) return rc;
     if ((rc = dev_alloc(h, &h->tmp_row, 4 * (n + 16)))) return rc;
   }
-  if (h->sweep_variant >= 3 && (rc = dev_alloc(h, &h->masks, (size_t)MASK_ROW_BYTES * (n + 16)))) return rc;
+  if (h->sweep_variant >= 3 && h->sweep_variant < 5 && (rc = dev_alloc(h, &h->masks, (size_t)MASK_ROW_BYTES * (n + 16)))) return rc;
+  if (h->sweep_variant >= 5) {
+    h->rstride = (int64_t)((n + 64 + 63) / 64 * 64);
+    if ((rc = dev_alloc(h, &h->fmask, 2 * (size_t)WAVE * (n + 16)))) return rc;
+    if ((rc = dev_alloc(h, &h->rmask, 8 * (size_t)HS_NUP * (size_t)h->rstride))) return rc;
+    if ((rc = dev_alloc(h, &h->fcnt, 4 * (n + 16)))) return rc;
+    if ((rc = dev_alloc(h, &h->rcnt, (size_t)HS_NUP * (size_t)h->rstride))) return rc;
+    if ((rc = dev_alloc(h, &h->full27_list, 4 * ((size_t)h->ncell + 16)))) return rc;
+  }
   if ((rc = dev_alloc(h, &h->dbg_buf, 8 * (64 + 4 * 4096)))) return rc;
   HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
   if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64 + 2 * (size_t)h->m[1] * h->m[2])))) return rc;

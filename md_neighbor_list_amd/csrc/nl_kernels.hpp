@@ -625,6 +625,15 @@ template <typename T> struct SweepArgs {
   int32_t pbc;                    // minimum-image mode: stencil cells reached through the periodic wrap are staged
                                   // at their image, coordinate -+ L (nl_set_periodic; not in the reference)
   int32_t z_origin;               // global z layer of local layer 0
+  // half-shell search (nl_half.hpp)
+  uint16_t* __restrict__ fmask;            // [n][64] F words: bit t of lane l of a slot = staged particle t*64 + l accepted
+  unsigned long long* __restrict__ rmask;  // [13][rstride] R words: bit b of (k, slot) = particle b of lower cell k accepted
+  uint32_t* __restrict__ fcnt;             // [n] forward count of a slot (HS_FINAL: counted by the 27-cell search)
+  uint8_t* __restrict__ rcnt;              // [13][rstride] popcount of the R words
+  int64_t rstride;
+  int32_t cells_per_block, ncells_grid;    // k_sweep_half / k_fill_half: cells a workgroup walks, cells of the launch
+  int32_t* __restrict__ full27_list;       // local cell indices of the cells k_full27 builds (irregular stencil)
+  int32_t* __restrict__ full27_count;      // their number: a meta word next to the status word, zeroed with it
   uint32_t* __restrict__ masks;  // [n] rows of 64 x 24 bits (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
   int32_t dbg;  // diagnostics only (NL_DEBUG_FLAGS): 1 = skip the search, 2 = skip the staging copy; 0 in production
@@ -776,17 +785,26 @@ struct CellCtx {
                        // reached through the low / no / high periodic face of that axis
 };
 
+// XCD-aware block -> cell order: blocks b, b+8, b+16.. share an XCD (and its L2), so give each XCD a contiguous range
+// of cells (a z-slab of the box) instead of every 8th cell.  Returns the linear index w of this block's cell among
+// the gridDim.x cells of the launch (x fastest, then y, then z).
+__device__ __forceinline__ int32_t xcd_cell_index() {
+  const int32_t nb = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+template <typename T> __device__ __forceinline__ bool cell_setup_at(const SweepArgs<T>& a, int lane, int32_t cx, int32_t cy, int32_t cz, CellCtx& c);
+
 // Maps the workgroup to its i-cell (XCD-aware) and loads the segment table.  Returns false for an empty cell.
 template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs<T>& a, int lane, CellCtx& c) {
-  // XCD-aware cell order: blocks b, b+8, b+16.. share an XCD (and its L2), so give each XCD a contiguous
-  // range of cells (a z-slab of the box) instead of every 8th cell.
-  int32_t w;
-  {
-    const int32_t nb = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nb >> 3, r = nb & 7;
-    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
+  const int32_t w = xcd_cell_index();
   const int32_t wy = (int32_t)fastdiv((uint32_t)w, a.div_mx), cx = w - wy * a.mx;
   const int32_t wz = (int32_t)fastdiv((uint32_t)wy, a.div_my), cy = wy - wz * a.my, cz = wz + (a.slab ? 1 : 0);
+  return cell_setup_at(a, lane, cx, cy, cz, c);
+}
+
+// The segment table of the i-cell (cx, cy, cz): cz is the local layer.
+template <typename T> __device__ __forceinline__ bool cell_setup_at(const SweepArgs<T>& a, int lane, int32_t cx, int32_t cy, int32_t cz, CellCtx& c) {
   const int32_t cell = cx + (cy + cz * a.my) * a.mx;
   // A build whose binning has flagged the particles as inconsistent with the slab description (ST_DOMAIN: a particle
   // in the wrong layer, or -- split slab builds -- a ghost count that does not match the data) may have overlapping
@@ -1156,6 +1174,12 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
     }
   }
 }
+
+}  // namespace nl
+
+#include "nl_half.hpp"
+
+namespace nl {
 
 // base_sorted[slot] = key_pointer[sorted_row[slot]]: the list offset of every row, in cell order, so that the placement
 // pass needs one (prefetchable) load per i-particle instead of two dependent ones.
