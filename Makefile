@@ -33,6 +33,15 @@ tools/make_list: tools/make_list.cpp include/neighlist_gpu.hpp include/nl_hip.h 
 oracle:
 	$(MAKE) -C oracle
 
+# CPU sanitizer build: the host shims over a host-memory stand-in of the C ABI, the input generator
+# and the oracle's restatement under AddressSanitizer + UndefinedBehaviorSanitizer.  CPU only -- never run on the GPU box.
+SANFLAGS := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1
+asan: build/sanitize_test
+build/sanitize_test: tests/sanitize/main.cpp tests/sanitize/abi_stub.cpp oracle/nl_oracle.c oracle/nl_oracle_impl.h $(CSRC)/nl_inputs.cpp include/neighlist_cpu.hpp include/neighlist_gpu.hpp include/nl_hip.h
+	@mkdir -p build
+	gcc $(SANFLAGS) -std=c11 -ffp-contract=off -fopenmp -Wall -Wextra -c -o build/san_oracle.o oracle/nl_oracle.c
+	$(CXX) $(SANFLAGS) -std=c++17 -Wall -Iinclude -o $@ tests/sanitize/main.cpp tests/sanitize/abi_stub.cpp $(CSRC)/nl_inputs.cpp build/san_oracle.o -fopenmp
+
 # ISA + resource usage of the kernels, for DESIGN.md / tuning
 asm:
 	@mkdir -p build
@@ -42,4 +51,4 @@ clean:
 	rm -f $(LIBDIR)/*.so tools/make_list build/*
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib inputs tools oracle asm clean
+.PHONY: all lib inputs tools oracle asm asan clean

@@ -50,8 +50,8 @@ static int cmp_i32(const void* a, const void* b) {
 /* sort_neighlist, make_list.cpp:120-128: ascending partners inside every CSR segment. */
 void nl_oracle_canonicalize(int64_t N, const int64_t* key_pointer, int32_t* sorted_list) {
   for (int64_t i = 0; i < N; i++)
-    qsort(sorted_list + key_pointer[i], (size_t)(key_pointer[i + 1] - key_pointer[i]), sizeof(int32_t),
-          cmp_i32);
+    if (key_pointer[i + 1] > key_pointer[i])  /* (an empty list may come as a null pointer: qsort must not see it) */
+      qsort(sorted_list + key_pointer[i], (size_t)(key_pointer[i + 1] - key_pointer[i]), sizeof(int32_t), cmp_i32);
 }
 
 /* Order-independent pair-set hash used for the known answers in SURVEY.md (Appendix A):
