@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--no-cfg4-baseline", action="store_true",
                     help="N = 1: skip the extra measurement of the 33.5 M box on one device (the N = 1 point of the strong-scaling series)")
     ap.add_argument("--profile-reps", type=int, default=10)
+    ap.add_argument("--dist", default="torch", choices=["torch", "cabi"],
+                    help="N > 1: halo exchange by torch.distributed p2p around nl_make_list_slab (md_neighbor_list_amd/slab.py), or the "
+                         "whole decomposed build inside the library (nl_make_list_distributed: pack kernel, counts, RCCL send/recv)")
     args = ap.parse_args()
 
     import torch
@@ -264,6 +267,16 @@ def main():
         nl.Initialize(n_total)
         step = lambda: nl.MakeNeighList(qd, n_total, sync=False)  # noqa: E731
         st = None
+    elif args.dist == "cabi":
+        from md_neighbor_list_amd.dist import DistributedNeighList
+
+        dn = DistributedNeighList(nl, rank, world, transport="host" if rehearsal else "rccl")
+        nl.Initialize(int(n_total / world * 1.6) + 65536)
+        n_own = dn.scatter(torch.from_numpy(q).to(dev), box, rc)
+        per = density * (2.0 / 3.0) * np.pi * rc**3
+        nl.set_capacity(int(n_own * per * 1.3) + 64 * n_own + 4096)
+        step = lambda: dn.build(sync=False)  # noqa: E731
+        st = None
     else:
         st = slab.setup(torch.from_numpy(q).to(dev), None, box, rc, rank, world)
         nl.Initialize(st.q_all.shape[0])
@@ -310,7 +323,7 @@ def main():
         # per-stage device time from HIP events on the launch stream (nl_profile_last_build), this rank's build
         stages = nl.profile_last_build(reps=args.profile_reps)
         info = nl.build_info()
-        n_loc, p_loc = (n_total if world == 1 else st.n_total), npairs_local
+        n_loc, p_loc = (n_total if world == 1 else st.n_total if st is not None else nl._n), npairs_local
         kernels = _stage_table(stages, info, n_loc, p_loc, vec_bytes, pos_bytes) if stages else []
         pmc, pmc_file = _newest_pmc(wl) if world == 1 else (None, None)
         traffic, valu = None, None
@@ -356,7 +369,8 @@ def main():
                        "n_particles": n_total, "half_pairs": npairs, "list_checksum": f"{checksum:016x}",
                        "half_pairs_reference": _reference_pairs(ka_key, npairs) if ka_key else None,
                        "offset_bits": info["offset_bits"],
-                       "decomposition": "none" if world == 1 else f"{world} z-slabs + 1-cell ghost layers (p2p)"},
+                       "decomposition": "none" if world == 1 else f"{world} z-slabs + 1-cell ghost layers (p2p; "
+                                        + ("nl_make_list_distributed" if args.dist == "cabi" else "torch.distributed around nl_make_list_slab") + ")"},
             "roofline": roofline,
         }
         if ka_key:

@@ -54,7 +54,8 @@ typedef enum nl_status {
                                 nl_get_*_csr / the transposed list after a wide build, or a build with
                                 nl_set_offset_width(32); the reference wraps silently there (neighlist_cpu.hpp:15,29) */
   NL_ERR_NO_DEVICE = 9,      /* no usable gfx950 device / wrong code object                                    */
-  NL_ERR_DOMAIN = 10         /* slab builds: a row particle outside the owned cells or a ghost inside them     */
+  NL_ERR_DOMAIN = 10,        /* slab builds: a row particle outside the owned cells or a ghost inside them     */
+  NL_ERR_COMM = 11           /* distributed builds: RCCL not loadable / a communicator call or the transport failed */
 } nl_status;
 
 const char* nl_status_string(int status);
@@ -152,6 +153,44 @@ int nl_make_list_slab_begin(nl_handle_t h, const void* q_dev, int32_t q_stride, 
                             int32_t n, int32_t n_ghost_lo, int32_t z_lo, int32_t z_hi, void* stream);
 int nl_make_list_slab_finish(nl_handle_t h, void* stream, int sync);
 
+/* ------------------------------------------------------------------------------- the decomposed build, whole */
+
+/* The domain-decomposed build with its halo exchange inside the library (no reference
+ * counterpart: the reference is single GPU, make_list.cu:122-127).  One process per GPU; rank r of `world` owns the
+ * cell layers nl_comm_layers returns for it (contiguous runs of the global mesh's z layers, as even as possible) and
+ * passes its owned particles only; per build the library packs the two boundary layers, tells the two z-neighbours how
+ * many particles come (the counts change from build to build in a moving system), moves the layers into the ghost rows
+ * of the caller's buffer and runs nl_make_list_slab on owned + ghosts.  Point-to-point only, no collective.
+ *
+ * nl_comm_create: RCCL over xGMI.  unique_id = the NL_UNIQUE_ID_BYTES bytes rank 0 got from nl_comm_unique_id and handed
+ *   to every rank out of band (ncclGetUniqueId / ncclCommInitRank).  RCCL is resolved at run time (dlopen: the copy the
+ *   process already uses, e.g. PyTorch's, else /opt/rocm/lib): NL_ERR_COMM if it cannot be loaded.  The transfer runs on
+ *   a communication stream under the binning of the owned layers (nl_make_list_slab_begin / _finish).
+ * nl_comm_create_callbacks: the caller supplies the transport, a blocking host-memory exchange
+ *   fn(user, peer_to, send, send_bytes, peer_from, recv, recv_bytes) -> 0 on success, called twice per message round in
+ *   the same order on every rank (first everybody sends to rank-1 and receives from rank+1, then the other way; a zero
+ *   byte count means that side is skipped).  For MPI / gloo / test harnesses; the layers are staged through pinned host memory.
+ * nl_make_list_distributed: q_dev = this rank's positions {x, y, z, w} (stride 4) with the GLOBAL particle id in w
+ *   (bit pattern of an int32 for NL_F32, of an int64 for NL_F64: NL_GID_IN_W), n_owned rows filled by the caller and room
+ *   for q_capacity rows: the ghosts are written behind the owned rows.  Every owned particle must lie in the rank's
+ *   layers (NL_ERR_DOMAIN otherwise: migrating particles between ranks is the caller's job); NL_ERR_CAPACITY when
+ *   owned + ghosts exceed q_capacity or the handle's n_max.  Rows (nl_get_half_csr ...) are those of the owned
+ *   particles and hold global ids, as after nl_make_list_slab.  Waits for the pack kernel and the counts (two host
+ *   synchronisations per build) before it returns, also with sync == 0.
+ * nl_distributed_ghosts: the ghost counts of the last build (rows [n_owned, n_owned + lo) and the hi rows behind). */
+typedef struct nl_comm_s* nl_comm_t;
+#define NL_UNIQUE_ID_BYTES 128
+typedef int (*nl_sendrecv_fn)(void* user, int peer_to, const void* send, size_t send_bytes, int peer_from, void* recv,
+                              size_t recv_bytes);
+int nl_comm_unique_id(void* id_out /* NL_UNIQUE_ID_BYTES */);
+int nl_comm_create(nl_comm_t* out, int rank, int world, const void* unique_id, int device_id);
+int nl_comm_create_callbacks(nl_comm_t* out, int rank, int world, nl_sendrecv_fn fn, void* user, int device_id);
+int nl_comm_destroy(nl_comm_t comm);
+int nl_comm_layers(nl_handle_t h, nl_comm_t comm, int32_t* z_lo, int32_t* z_hi);
+int nl_make_list_distributed(nl_handle_t h, nl_comm_t comm, void* q_dev, int32_t q_capacity, int32_t n_owned, void* stream,
+                             int sync);
+int nl_distributed_ghosts(nl_comm_t comm, int32_t* n_ghost_lo, int32_t* n_ghost_hi);
+
 /* Waits for the last enqueued build and returns its status (replaces the harness's
  * checkCudaErrors(cudaDeviceSynchronize()), make_list.cu:128). */
 int nl_synchronize(nl_handle_t h);
@@ -196,6 +235,22 @@ int nl_get_full_transposed(nl_handle_t h, const int32_t** list_dev, const int32_
 /* number_of_pairs(): P, the half-pair count (neighlist_cpu.hpp:437-439).  The GPU class returns the sum of the
  * full counts = 2P (neighlist_gpu.hpp:484-487); the C++ shim doubles it.  Synchronises. */
 int nl_number_of_pairs(nl_handle_t h, int64_t* npairs);
+
+/* ------------------------------------------------------------------------------------- periodic re-sorting */
+
+/* The physical re-sort the reference declares and never performs: SORT_FREQ = 50 (neighlist_gpu.hpp:72), CopyGather
+ * (neighlist_gpu.hpp:144-151), SortPtclData (neighlist_cpu.hpp:176-180, its call commented out at :421).  A build
+ * already sorts a COPY of the positions into cell order; an MD loop that permutes its own per-particle arrays the same
+ * way every SORT_FREQ builds keeps them spatially coherent, which makes the binning pass of the next builds and every
+ * gather through the list (forces) faster.
+ *   nl_get_cell_order: order[s] = input index of the particle the last build placed at cell-ordered slot s
+ *     (the reference's ptcl_id_in_mesh, neighlist_gpu.hpp:153-199), a device pointer valid until the next build.
+ *   nl_resort: array[s] <- array[order[s]] in place for one per-particle array of elem_bytes (4, 8, 12, 16, 24 or 32)
+ *     per particle: positions, velocities, ids, ... -- call it once per array, then rebuild: the new list is the list
+ *     of the permuted particles (indices are the NEW positions in the arrays).  Enqueued on `stream`; single-device
+ *     builds only.  Synchronises with the last build first. */
+int nl_get_cell_order(nl_handle_t h, const int32_t** order_dev, int32_t* n);
+int nl_resort(nl_handle_t h, void* array_dev, size_t elem_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------- a consumer */
 

@@ -10,12 +10,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnl_hip.so")
 NL_F32, NL_F64 = 0, 1
 NL_OK = 0
 (NL_ERR_ARG, NL_ERR_NOMEM, NL_ERR_OUT_OF_BOX, NL_ERR_CAPACITY, NL_ERR_HIP, NL_ERR_STATE, NL_ERR_MESH,
- NL_ERR_INDEX_OVERFLOW, NL_ERR_NO_DEVICE, NL_ERR_DOMAIN) = range(1, 11)
+ NL_ERR_INDEX_OVERFLOW, NL_ERR_NO_DEVICE, NL_ERR_DOMAIN, NL_ERR_COMM) = range(1, 12)
+NL_UNIQUE_ID_BYTES = 128
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t)
+_P, _I32, _I64, _SZ, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_double
 NL_NUM_STAGES = 7
 STAGE_NAMES = ("hash", "cell_scan", "reorder", "count", "row_scan", "fill", "total")
 
 # every symbol include/nl_hip.h declares: (name, restype, argtypes)
-_P, _I32, _I64, _SZ, _D = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_double
 PROTOTYPES = {
     "nl_status_string": (C.c_char_p, [C.c_int]),
     "nl_create": (C.c_int, [C.POINTER(_P), C.c_int, _D, _D, _D, _D, C.c_int]),
@@ -30,12 +32,21 @@ PROTOTYPES = {
     "nl_make_list_slab_begin": (C.c_int, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "nl_make_list_slab_finish": (C.c_int, [_P, _P, C.c_int]),
     "nl_synchronize": (C.c_int, [_P]),
+    "nl_comm_unique_id": (C.c_int, [_P]),
+    "nl_comm_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, _P, C.c_int]),
+    "nl_comm_create_callbacks": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int, SENDRECV_FN, _P, C.c_int]),
+    "nl_comm_destroy": (C.c_int, [_P]),
+    "nl_comm_layers": (C.c_int, [_P, _P, C.POINTER(_I32), C.POINTER(_I32)]),
+    "nl_make_list_distributed": (C.c_int, [_P, _P, _P, _I32, _I32, _P, C.c_int]),
+    "nl_distributed_ghosts": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
     "nl_get_half_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "nl_get_full_csr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "nl_get_half_csr64": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "nl_get_full_csr64": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "nl_list_checksum": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(_I64)]),
     "nl_set_offset_width": (C.c_int, [_P, C.c_int]),
+    "nl_get_cell_order": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I32)]),
+    "nl_resort": (C.c_int, [_P, _P, _SZ, _P]),
     "nl_lj_forces": (C.c_int, [_P, _P, _I32, _D, _D, _D, _P, _P]),
     "nl_get_full_transposed": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64), C.POINTER(_I32)]),
     "nl_number_of_pairs": (C.c_int, [_P, C.POINTER(_I64)]),

@@ -74,6 +74,7 @@ struct nl_handle_s {
   uint32_t* fcnt = nullptr;
   uint8_t* rcnt = nullptr;
   int32_t* full27_list = nullptr;
+  void* resort_buf = nullptr;      // scratch of nl_resort (32 bytes per particle), allocated on first use
   int64_t rstride = 0;
   bool b_half = false;             // this build: half-shell search
   int half_cpb = 4;                // cells a workgroup of k_sweep_half walks (NL_HALF_CPB)
@@ -602,6 +603,27 @@ __global__ void __launch_bounds__(256) k_list_checksum(const OFF* __restrict__ k
   if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
 }
 
+// CopyGather (neighlist_gpu.hpp:144-151) / Gather + SortPtclData (neighlist_cpu.hpp:170-180): dst[s] = src[order[s]]
+// for elements of W 32-bit words.
+template <int W>
+__global__ void __launch_bounds__(256) k_gather_words(const uint32_t* __restrict__ src, const int32_t* __restrict__ order, int32_t n,
+                                                      uint32_t* __restrict__ dst) {
+  const int32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t* p = src + (size_t)order[s] * W;
+  uint32_t* d = dst + (size_t)s * W;
+  if constexpr (W % 4 == 0) {
+#pragma unroll
+    for (int k = 0; k < W / 4; k++) reinterpret_cast<uint4*>(d)[k] = reinterpret_cast<const uint4*>(p)[k];
+  } else if constexpr (W % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < W / 2; k++) reinterpret_cast<uint2*>(d)[k] = reinterpret_cast<const uint2*>(p)[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; k++) d[k] = p[k];
+  }
+}
+
 int get_csr(nl_handle_t h, bool full, int width, const void** key_pointer_dev, const int32_t** list_dev,
             const int32_t** number_of_partners_dev, int64_t* nentries) {
   if (!h) return NL_ERR_ARG;
@@ -634,6 +656,7 @@ const char* nl_status_string(int s) {
     case NL_ERR_INDEX_OVERFLOW: return "more than INT32_MAX list entries behind a 32-bit key_pointer";
     case NL_ERR_NO_DEVICE: return "no usable HIP device";
     case NL_ERR_DOMAIN: return "particle outside the layers declared for this rank";
+    case NL_ERR_COMM: return "communication failed (RCCL not loadable, communicator or transport error)";
     default: return "unknown status";
   }
 }
@@ -712,7 +735,7 @@ int nl_destroy(nl_handle_t h) {
   if (!h) return NL_ERR_ARG;
   (void)hipSetDevice(h->device);
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
-  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->kp_alt, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->fmask, h->rmask, h->fcnt, h->rcnt, h->full27_list, h->dbg_buf, h->cell_count,
+  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->kp_alt, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->fmask, h->rmask, h->fcnt, h->rcnt, h->full27_list, h->resort_buf, h->dbg_buf, h->cell_count,
                   h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -745,6 +768,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   if ((rc = dev_alloc(h, &h->key_pointer, 8 * (n + 32)))) return rc;  // int32 or int64 offsets (b_wide)
   if (h->kp_alt) (void)hipFree(h->kp_alt), h->kp_alt = nullptr;
   h->kp_alt_valid = false;
+  if (h->resort_buf) (void)hipFree(h->resort_buf), h->resort_buf = nullptr;
   if ((rc = dev_alloc(h, &h->progress, 4 * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->base_sorted, 8 * (n + 16)))) return rc;
   {
@@ -1003,6 +1027,47 @@ int nl_list_checksum(nl_handle_t h, uint64_t* checksum, int64_t* nentries) {
   return NL_OK;
 }
 
+int nl_get_cell_order(nl_handle_t h, const int32_t** order_dev, int32_t* n) {
+  if (!h) return NL_ERR_ARG;
+  int rc = nl_synchronize(h);
+  if (rc) return rc;
+  if (order_dev) *order_dev = h->sorted_row;
+  if (n) *n = h->n;
+  return NL_OK;
+}
+
+int nl_resort(nl_handle_t h, void* array_dev, size_t elem_bytes, void* stream) {
+  if (!h || !array_dev || elem_bytes == 0 || elem_bytes % 4 != 0 || elem_bytes > 32 || elem_bytes == 20 || elem_bytes == 28)
+    return fail(h, NL_ERR_ARG);
+  int rc = nl_synchronize(h);  // the permutation is the last build's
+  if (rc) return rc;
+  if (h->b_slab || h->n_rows != h->n) return fail(h, NL_ERR_STATE);  // a permutation of the caller's own particles
+  HIPCHK(h, hipSetDevice(h->device));
+  const int32_t n = h->n;
+  if (n == 0) return NL_OK;
+  if (!h->resort_buf) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 32 * ((size_t)h->n_max + 16)) != hipSuccess) return fail(h, NL_ERR_NOMEM);
+    h->resort_buf = p;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (s != h->last_stream) HIPCHK(h, hipStreamSynchronize(h->last_stream));
+  const uint32_t* src = static_cast<const uint32_t*>(array_dev);
+  uint32_t* buf = static_cast<uint32_t*>(h->resort_buf);
+  const dim3 grid((n + 255) / 256), block(256);
+  switch (elem_bytes / 4) {
+    case 1: hipLaunchKernelGGL(k_gather_words<1>, grid, block, 0, s, src, h->sorted_row, n, buf); break;
+    case 2: hipLaunchKernelGGL(k_gather_words<2>, grid, block, 0, s, src, h->sorted_row, n, buf); break;
+    case 3: hipLaunchKernelGGL(k_gather_words<3>, grid, block, 0, s, src, h->sorted_row, n, buf); break;
+    case 4: hipLaunchKernelGGL(k_gather_words<4>, grid, block, 0, s, src, h->sorted_row, n, buf); break;
+    case 6: hipLaunchKernelGGL(k_gather_words<6>, grid, block, 0, s, src, h->sorted_row, n, buf); break;
+    default: hipLaunchKernelGGL(k_gather_words<8>, grid, block, 0, s, src, h->sorted_row, n, buf); break;
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(array_dev, buf, elem_bytes * (size_t)n, hipMemcpyDeviceToDevice, s));
+  return NL_OK;
+}
+
 int nl_set_offset_width(nl_handle_t h, int bits) {
   if (!h || (bits != 0 && bits != 32 && bits != 64)) return fail(h, NL_ERR_ARG);
   HIPCHK(h, hipSetDevice(h->device));
@@ -1172,3 +1237,4 @@ int nl_device_synchronize(void) { return hipDeviceSynchronize() == hipSuccess ? 
 
 #include "nl_transpose.inc"
 #include "nl_consumer.inc"
+#include "nl_dist.inc"

@@ -280,6 +280,23 @@ class NeighListGPU:
               "nl_lj_forces")
         return f
 
+    # ------------------------------------------------------------------ periodic re-sorting (SORT_FREQ)
+    def cell_order(self):
+        """order[s] = input index of the particle at cell-ordered slot s of the last build (nl_get_cell_order; the
+        reference's ptcl_id_in_mesh).  View, valid until the next build."""
+        ptr, n = C.c_void_p(), C.c_int32()
+        check(self._lib.nl_get_cell_order(self._h, C.byref(ptr), C.byref(n)), "nl_get_cell_order")
+        return _as_tensor(ptr.value, (n.value,), "<i4", self, self.device)
+
+    def resort(self, *arrays):
+        """Permutes per-particle device arrays in place into the cell order of the last build (nl_resort): the re-sort
+        the reference declares (SORT_FREQ, CopyGather, SortPtclData) and never calls.  Rebuild afterwards."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        for t in arrays:
+            if not isinstance(t, torch.Tensor) or t.device.type != "cuda" or not t.is_contiguous() or t.shape[0] != self._n:
+                raise TypeError("resort() takes contiguous device tensors with one leading entry per particle")
+            check(self._lib.nl_resort(self._h, t.data_ptr(), t.element_size() * (t.numel() // max(t.shape[0], 1)), stream), "nl_resort")
+
     # ------------------------------------------------------------------ introspection
     def sorted_state(self):
         """(cell_start, sorted_row) of the last build -- for tests of the hash/sort stage."""

@@ -36,6 +36,8 @@ def worker(rank, world, port, mode, case, ret):
             q = np.ascontiguousarray(q[~np.isin(iz, case[5])])
             n = len(q)
         pbc = mode == "hip_pbc"  # minimum-image mode (nl_set_periodic): the end ranks' ghost layers are images
+        if mode in ("cabi", "cabi_rccl1"):
+            return worker_cabi(rank, world, mode, q, box, rc, ret)
         dev = "cuda" if mode in ("hip", "hip_pbc") else "cpu"
         qt = torch.from_numpy(q).to(dev)
         st = slab.setup(qt, None, box, rc)
@@ -93,6 +95,57 @@ def worker(rank, world, port, mode, case, ret):
         raise e
     finally:
         dist.destroy_process_group()
+
+
+def worker_cabi(rank, world, mode, q, box, rc, ret):
+    """nl_make_list_distributed (pack kernel, count + halo exchange and slab build inside libnl_hip.so) over the host
+    transport (gloo), twice: the second time every particle has moved -- boundary-layer populations change, particles
+    change layer and owner (the test migrates them between ranks, as an MD code would) -- with the SAME handle and
+    communicator.  The union of the ranks' rows must be the oracle's global list both times."""
+    import torch
+    import torch.distributed as dist
+
+    from md_neighbor_list_amd import NeighListGPU
+    from md_neighbor_list_amd.dist import DistributedNeighList
+    from oracle import pyoracle as po
+
+    n = len(q)
+    tdt = torch.float32 if q.dtype == np.float32 else torch.float64
+    nl = NeighListGPU(rc, *box, dtype=tdt)
+    nl.Initialize(int(2.2 * n / world) + 8192)
+    dn = DistributedNeighList(nl, rank, world, transport="rccl" if mode == "cabi_rccl1" else "host")
+    rng = np.random.default_rng(5)
+    ghosts_seen = []
+    for rnd in range(2):
+        if rnd:  # everybody moves by up to 0.45 cells; coordinates stay inside the box
+            q = q.copy()
+            q[:, :3] += rng.uniform(-1.5, 1.5, size=(n, 3)).astype(q.dtype)
+            q[:, :3] = np.mod(q[:, :3], np.array(box, dtype=q.dtype))
+            q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=q.dtype), q.dtype.type(0)))
+        dn.scatter(torch.from_numpy(q).cuda(), box, rc)
+        for sync in (True, False):
+            dn.build(sync=sync)
+            nl.synchronize()
+            kp = nl.key_pointer().cpu().numpy()
+            sl = nl.sorted_list().cpu().numpy()
+            assert len(kp) == dn.n_owned + 1
+            mine = pairs_of(kp, sl, dn.gid_owned.cpu().numpy())
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (mine, dn.n_owned, dn.n_ghost_lo, dn.n_ghost_hi))
+            if rank == 0:
+                ref = po.build(q, rc, box)
+                want = np.sort(pairs_of(ref.key_pointer, ref.sorted_list))
+                got = np.sort(np.concatenate([g[0] for g in gathered]))
+                assert sum(g[1] for g in gathered) == n
+                assert len(got) == len(want) == ref.npairs, (rnd, len(got), len(want))
+                assert np.array_equal(got, want), rnd
+        ghosts_seen.append((dn.n_ghost_lo, dn.n_ghost_hi))
+    g2 = [None] * world
+    dist.all_gather_object(g2, ghosts_seen)
+    if rank == 0:
+        if world > 1:
+            assert any(a[0] != a[1] for a in g2), g2  # the ghost counts did change between the two builds
+        ret.put(("ok", 0, g2))
 
 
 def run(world, mode, case, timeout=600):

@@ -880,3 +880,53 @@ def test_config5_full_size(key):
         r2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
         want = np.nonzero(~(r2.astype(np.float64) > rc2) & (np.arange(len(q)) > i))[0]
         assert np.array_equal(np.sort(sl[kp[i]:kp[i + 1]].cpu().numpy()), want.astype(np.int32))
+
+
+# ---------------------------------------------------------------------------------------------- periodic re-sorting
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_resort_then_rebuild_equals_the_oracle_on_the_permuted_input(dtype):
+    """SURVEY section 8 f2 (the reference's dead SORT_FREQ / CopyGather / SortPtclData hooks, neighlist_gpu.hpp:72,144-151,
+    neighlist_cpu.hpp:176-180,421) as a library feature: nl_resort permutes the caller's arrays into the last build's
+    cell order; the list built afterwards must be exactly the ORACLE's list of the permuted particles, and -- mapped
+    back through the carried ids -- the oracle's pair set of the original particles.  Repeated, as an MD loop would."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    n, box, rc = 40000, (34.2, 30.0, 41.0), 3.3
+    q, box = inputs.uniform_box(n, dtype=dtype, seed=31, box=box)
+    ref0 = _po().build(q, rc, box)
+    kp0 = ref0.key_pointer
+    lo0 = np.repeat(np.arange(n, dtype=np.int64), np.diff(kp0))
+    pairs0 = np.unique(lo0 * n + ref0.sorted_list.astype(np.int64))
+    nl = NeighListGPU(rc, *box, dtype=torch.float32 if dtype == np.float32 else torch.float64)
+    nl.Initialize(n)
+    qd = torch.from_numpy(q).cuda()
+    ids = torch.arange(n, dtype=torch.int32, device="cuda")
+    vel = torch.from_numpy(np.random.default_rng(1).normal(size=(n, 3)).astype(dtype)).cuda()  # a 12- / 24-byte array
+    vel0 = vel.clone()
+    nl.MakeNeighList(qd, n)
+    for rnd in range(2):
+        order = nl.cell_order().cpu().numpy()
+        assert np.array_equal(np.sort(order), np.arange(n))  # a permutation
+        cell, _ = _po().cells(q, rc, box)
+        q_host_before = qd.cpu().numpy()
+        nl.resort(qd, ids, vel)
+        assert np.array_equal(qd.cpu().numpy(), q_host_before[order])  # array[s] <- array[order[s]]
+        nl.MakeNeighList(qd, n)
+        qp = qd.cpu().numpy()
+        idp = ids.cpu().numpy().astype(np.int64)
+        assert np.array_equal(qp, q[idp]) and np.array_equal(vel.cpu().numpy(), vel0.cpu().numpy()[idp])
+        # cell order: the cells of the stored particles are non-decreasing
+        cellp, _ = _po().cells(qp, rc, box)
+        assert np.all(np.diff(cellp) >= 0)
+        ref = _po().build(qp, rc, box)  # the oracle on the permuted input
+        kp, sl = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
+        assert np.array_equal(kp.astype(np.int64), ref.key_pointer)
+        assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+        # ids mapped back: the same set of unordered pairs as the original list
+        lo = np.repeat(np.arange(n, dtype=np.int64), np.diff(kp))
+        a, b = idp[lo], idp[sl.astype(np.int64)]
+        pairs = np.unique(np.minimum(a, b) * n + np.maximum(a, b))
+        assert np.array_equal(pairs, pairs0)
+        # a second round re-sorts an already sorted system: the order is the identity up to ties inside a cell

@@ -58,6 +58,29 @@ def test_slab_union_equals_global_list_gpu(world, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,case", [
+    (2, (60000, (30.0, 30.0, 66.0), 3.3, "float32", 83)),
+    (3, (50000, (25.0, 25.0, 80.0), 3.3, "float64", 84)),
+    (3, (40000, (25.0, 25.0, 80.0), 3.3, "float32", 85, [7, 8])),  # two empty layers: a rank with nothing to send upwards
+])
+def test_distributed_build_behind_the_c_abi_with_moving_particles(world, case):
+    """nl_comm_create_callbacks + nl_make_list_distributed: the pack kernel, the count and halo
+    exchange and the slab build inside the library, the transport being gloo; a second pair of builds after every
+    particle has moved (ghost counts change, particles change layer and owner)."""
+    res = run(world, "cabi", case)
+    assert res[0] == "ok"
+
+
+@pytest.mark.gpu
+def test_distributed_build_over_rccl_with_one_rank():
+    """nl_comm_unique_id + nl_comm_create (RCCL resolved at run time, ncclCommInitRank) with a world of one -- all a
+    one-GPU box can host: the communicator comes up and the build is the whole-box build.  The N > 1 RCCL exchange
+    itself (grouped ncclSend / ncclRecv) has not run on hardware: DESIGN.md section 6."""
+    res = run(1, "cabi_rccl1", (30000, (25.0, 25.0, 40.0), 3.3, "float32", 86))
+    assert res[0] == "ok"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case", [
     (2, (30000, (20.0, 22.0, 40.0), 3.3, "float32", 91)),   # 12 layers: the end ranks' ghosts are periodic images
     (3, (30000, (21.0, 20.0, 31.0), 3.3, "float64", 92)),   # 9 layers, 3 + 3 + 3
 ])

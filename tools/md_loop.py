@@ -3,7 +3,7 @@
   * a Verlet list built with cut-off rc + skin, reused until some particle has moved more than skin / 2
     (max displacement since the last build), then rebuilt;
   * every SORT_FREQ rebuilds (the reference declares SORT_FREQ = 50 and never uses it, neighlist_gpu.hpp:72) the
-    particle arrays are permuted into the build's cell order (nl_get_sorted), which speeds up both the next builds
+    particle arrays are permuted into the build's cell order (nl_resort), which speeds up both the next builds
     and the force gathers (profiles/r01_force_consumer_timing.txt);
   * forces from nl_lj_forces on the full list (one gather per row, no atomics).
 The list has no minimum image (neither has the reference): the droplet sits in the middle of an open box.
@@ -53,9 +53,8 @@ class Simulation:
 
     def rebuild(self):
         if self.builds and self.builds % SORT_FREQ == 0:
-            # re-sort: the previous build's cell order becomes the storage order
-            order = self.nl.sorted_state()[1].long()
-            self.q, self.v, self.ids = self.q[order].contiguous(), self.v[order].contiguous(), self.ids[order]
+            # re-sort: the previous build's cell order becomes the storage order (nl_resort, in place)
+            self.nl.resort(self.q, self.v, self.ids)
             self.sorts += 1
         self.nl.MakeNeighList(self.q, len(self.q))
         self.q_built = self.q.clone()
