@@ -77,6 +77,8 @@ struct nl_handle_s {
   void* resort_buf = nullptr;      // scratch of nl_resort (32 bytes per particle), allocated on first use
   int64_t rstride = 0;
   bool b_half = false;             // this build: half-shell search
+  int32_t b_isplit = 1;            // this build, two-sweep path: workgroups per cell
+  int isplit_env = 0;              // NL_ISPLIT: 0 = by density
   int half_cpb = 4;                // cells a workgroup of k_sweep_half walks (NL_HALF_CPB)
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps;
                                    // 3 (default): COUNT keeping hit masks + mask expansion
@@ -258,6 +260,7 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.status = h->status;
   a.masks = h->masks;
   a.fmask = h->fmask, a.rmask = h->rmask, a.fcnt = h->fcnt, a.rcnt = h->rcnt, a.rstride = h->rstride;
+  a.isplit = 1, a.cells_per_block = 1, a.ncells_grid = 0;
   a.full27_list = h->full27_list;
   a.full27_count = reinterpret_cast<int32_t*>(h->status) + META_FULL27;
   a.pbc = h->pbc ? 1 : 0;
@@ -325,13 +328,17 @@ template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h,
     }
     return;
   }
+  // two distance sweeps.  Dense cells are shared by several workgroups (sweep_cell): about 64 i-particles each
+  SweepArgs<T> a2 = a;
+  a2.isplit = h->b_isplit;
+  const int32_t grid2 = ncells_i * h->b_isplit;
   if (mode == MODE_COUNT) {
     if constexpr (sizeof(T) == 4)
-      hipLaunchKernelGGL((k_sweep_count_f32<FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+      hipLaunchKernelGGL((k_sweep_count_f32<FULL, PBC>), dim3(grid2), dim3(SWEEP_WAVES * WAVE), 0, s, a2);
     else
-      hipLaunchKernelGGL((k_sweep<T, MODE_COUNT, FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+      hipLaunchKernelGGL((k_sweep<T, MODE_COUNT, FULL, PBC>), dim3(grid2), dim3(SWEEP_WAVES * WAVE), 0, s, a2);
   } else
-    hipLaunchKernelGGL((k_sweep<T, MODE_FILL, FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+    hipLaunchKernelGGL((k_sweep<T, MODE_FILL, FULL, PBC>), dim3(grid2), dim3(SWEEP_WAVES * WAVE), 0, s, a2);
 }
 
 template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) {
@@ -368,6 +375,13 @@ void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int
   h->b_use_masks = h->b_variant >= 3 && h->b_variant < 5 && h->masks && sparse_enough;
   // 64-bit list offsets as soon as the list this handle can hold exceeds what an int32 key_pointer can address
   // (the reference's own limit, neighlist_cpu.hpp:15,29); nl_set_offset_width overrides.
+  {  // dense cells: one workgroup per ~64 i-particles of a cell (two-sweep path only)
+    const double per_cell = ncl > 0 ? (double)n / (double)ncl : 0.0;
+    int32_t sp = h->isplit_env > 0 ? h->isplit_env : (int32_t)(per_cell / 64.0 + 0.5);
+    sp = std::max(1, std::min(sp, 32));
+    if ((int64_t)sp * ncl > 2000000000LL) sp = 1;
+    h->b_isplit = (h->b_use_masks || h->b_half) ? 1 : sp;
+  }
   h->b_wide = h->offset_width == 64 || (h->offset_width == 0 && h->capacity > 2147483647LL);
   h->kp_alt_valid = false;
 }
@@ -719,6 +733,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : atoi(v) >= 6 ? 6 : atoi(v) == 5 ? 5 : 3;
+    if (const char* v = getenv("NL_ISPLIT")) h->isplit_env = std::max(0, atoi(v));
     if (const char* v = getenv("NL_HALF_CPB")) h->half_cpb = std::max(1, atoi(v));
     if (const char* v = getenv("NL_OFFSET_WIDTH")) h->offset_width = atoi(v) == 64 ? 64 : atoi(v) == 32 ? 32 : 0;
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;

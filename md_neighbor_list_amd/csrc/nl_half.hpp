@@ -262,12 +262,23 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE, (sizeof(T) == 4 ? 7 : 4)) k
   constexpr int NPRE = (HS_NSEG + SWEEP_WAVES - 1) / SWEEP_WAVES;  // segments per wave: wave, wave + 4, ...
   const uint32_t st_word = *a.status;  // (read with the first cell table)
   const int32_t w0 = xcd_cell_index() * a.cells_per_block, w1 = min(w0 + a.cells_per_block, a.ncells_grid);
+  // diagnostics (NL_DEBUG_FLAGS & 4, tools/half_phases.py): shader cycles of every wave per phase, summed into dbg_buf[8 + phase]
+  uint64_t tprev = (a.dbg & 4) ? __builtin_amdgcn_s_memtime() : 0;
+  auto stamp = [&](int phase, bool drain) {
+    if (a.dbg & 4) {
+      if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      if (lane == 0) atomicAdd(a.dbg_buf + 8 + phase, (unsigned long long)(now - tprev));
+      tprev = now;
+    }
+  };
   for (int32_t w = w0; w < w1; w++) {
     if (w != w0) __syncthreads();  // everyone is done with the previous cell's LDS
     HalfRaw raw;
     HalfCtx c;
     half_issue(a, lane, w, raw);
     half_finish(a, lane, raw, c);
+    stamp(0, true);
     if (st_word & ST_DOMAIN) return;  // an inconsistent cell table (see cell_setup_at): nobody walks it
     if (c.own_regular) {
       Pos<T> pre[NPRE];
@@ -303,8 +314,12 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE, (sizeof(T) == 4 ? 7 : 4)) k
         }
       }
     }
+    stamp(1, true);
     __syncthreads();
+    stamp(2, false);
     half_search_cell<T, FULL, PBC>(a, c, tile, rw, tid, lane, wave);
+    stamp(3, false);
+    if ((a.dbg & 4) && lane == 0) atomicAdd(a.dbg_buf + 15, 1ull);
   }
 }
 

@@ -632,6 +632,7 @@ template <typename T> struct SweepArgs {
   uint8_t* __restrict__ rcnt;              // [13][rstride] popcount of the R words
   int64_t rstride;
   int32_t cells_per_block, ncells_grid;    // k_sweep_half / k_fill_half: cells a workgroup walks, cells of the launch
+  int32_t isplit;                          // two-sweep path: workgroups per cell (each a part of the cell's i-particles)
   int32_t* __restrict__ full27_list;       // local cell indices of the cells k_full27 builds (irregular stencil)
   int32_t* __restrict__ full27_count;      // their number: a meta word next to the status word, zeroed with it
   uint32_t* __restrict__ masks;  // [n] rows of 64 x 24 bits (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
@@ -974,9 +975,17 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
   }
 }
 
+// LDS batch of the sweeps.  The two distance sweeps of fp64 builds (dense cells: BASELINE config 5) take half the batch:
+// 20 KB instead of 40 KB per workgroup, so that registers (5-6 waves per SIMD), not LDS (4), bound their occupancy;
+// a staged particle is tested against ~60 i-particles there, so twice the staging steps cost little.
+template <typename T, int MODE> constexpr int sweep_cap() {
+  return sizeof(T) == 8 && MODE != MODE_COUNT_MASKS ? SweepCfg<T>::CAP / 2 : SweepCfg<T>::CAP;
+}
+
 template <typename T, int MODE, bool FULL = false, bool PBC = false>
 __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
-  __shared__ Pos<T> tile[SweepCfg<T>::CAP];
+  constexpr int CAP = sweep_cap<T, MODE>();
+  __shared__ Pos<T> tile[CAP];
   if (MODE == MODE_FILL) {
     if (a.total[0] > a.capacity) {  // uniform: every workgroup leaves, nothing is written out of bounds
       if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
@@ -985,8 +994,21 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   CellCtx c;
-  if (!cell_setup(a, lane, c)) return;
-  cell_search<T, MODE, SweepCfg<T>::CAP, SWEEP_WAVES, FULL, PBC>(a, c, tile, tid, lane, wave);
+  if (MODE == MODE_COUNT_MASKS || a.isplit <= 1) {
+    if (!cell_setup(a, lane, c)) return;
+  } else {
+    // Dense cells (hundreds of particles: 2 x cut-off) are shared by a.isplit workgroups, each taking a contiguous part
+    // of the cell's i-particles against the whole stream: a box of a few thousand cells otherwise leaves the last
+    // quarter of the chip idle behind a handful of 2 ms workgroups.  Parts of a cell are neighbours in the XCD order.
+    const int32_t wp = xcd_cell_index(), w = wp / a.isplit, part = wp - w * a.isplit;
+    const int32_t wy = (int32_t)fastdiv((uint32_t)w, a.div_mx), cx = w - wy * a.mx;
+    const int32_t wz = (int32_t)fastdiv((uint32_t)wy, a.div_my), cy = wy - wz * a.my, cz = wz + (a.slab ? 1 : 0);
+    if (!cell_setup_at(a, lane, cx, cy, cz, c)) return;
+    const int32_t lo = (int32_t)((int64_t)c.ni * part / a.isplit), hi = (int32_t)((int64_t)c.ni * (part + 1) / a.isplit);
+    c.ibeg += lo, c.ni = hi - lo;
+    if (c.ni <= 0) return;
+  }
+  cell_search<T, MODE, CAP, SWEEP_WAVES, FULL, PBC>(a, c, tile, tid, lane, wave);
 }
 
 template <typename T, int MODE, bool FULL = false, bool PBC = false>

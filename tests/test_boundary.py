@@ -20,7 +20,9 @@ def declared_symbols():
 def test_header_declares_the_expected_surface():
     syms = declared_symbols()
     for must in ("nl_create", "nl_initialize", "nl_make_list", "nl_make_list_slab", "nl_get_half_csr",
-                 "nl_get_full_transposed", "nl_number_of_pairs", "nl_destroy", "nl_buf_alloc"):
+                 "nl_get_full_transposed", "nl_number_of_pairs", "nl_destroy", "nl_buf_alloc",
+                 "nl_comm_create", "nl_comm_create_callbacks", "nl_make_list_distributed", "nl_get_half_csr64",
+                 "nl_set_offset_width", "nl_list_checksum", "nl_resort", "nl_get_cell_order"):
         assert must in syms
 
 
@@ -49,6 +51,19 @@ def test_argument_errors_without_a_device():
     assert lib.nl_create(None, 0, 3.3, 10.0, 10.0, 10.0, 0) == _lib.NL_ERR_ARG
     assert lib.nl_destroy(None) == _lib.NL_ERR_ARG
     assert lib.nl_make_list(None, None, 4, 0, None, 1) == _lib.NL_ERR_ARG
+    # the decomposed build's entry points: argument checks come before any device or RCCL call
+    c = ctypes.c_void_p()
+    uid = (ctypes.c_uint8 * _lib.NL_UNIQUE_ID_BYTES)()
+    assert lib.nl_comm_create(ctypes.byref(c), 0, 0, uid, 0) == _lib.NL_ERR_ARG        # world < 1
+    assert lib.nl_comm_create(ctypes.byref(c), 2, 2, uid, 0) == _lib.NL_ERR_ARG        # rank >= world
+    assert lib.nl_comm_create(ctypes.byref(c), 0, 2, None, 0) == _lib.NL_ERR_ARG       # no unique id
+    assert lib.nl_comm_create(None, 0, 1, uid, 0) == _lib.NL_ERR_ARG
+    assert lib.nl_comm_create_callbacks(ctypes.byref(c), 0, 2, _lib.SENDRECV_FN(), None, 0) == _lib.NL_ERR_ARG  # no transport
+    assert lib.nl_comm_destroy(None) == _lib.NL_ERR_ARG
+    assert lib.nl_comm_unique_id(None) == _lib.NL_ERR_ARG
+    assert lib.nl_make_list_distributed(None, None, None, 0, 0, None, 1) == _lib.NL_ERR_ARG
+    assert lib.nl_resort(None, None, 16, None) == _lib.NL_ERR_ARG
+    assert lib.nl_set_offset_width(None, 64) == _lib.NL_ERR_ARG
 
 
 def test_product_never_imports_the_oracle():

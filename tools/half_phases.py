@@ -24,7 +24,7 @@ for name in sys.argv[1:] or ["cfg2"]:
     for _ in range(reps):
         nl.MakeNeighList(qd, len(q))
     nl._lib.nl_debug_read(nl._h, buf.ctypes.data, len(buf), 1)
-    v = buf[8:14].astype(np.float64)
+    v = buf[8:12].astype(np.float64)
     nw = float(buf[15]) or 1.0
-    names = ["table", "staging", "barrier 1", "search", "barrier 2", "write-out"]
+    names = ["table", "staging", "barrier", "search + barrier + R write-out"]
     print(f"{name}: cycles per wave and cell: " + "  ".join(f"{n} {x / nw:.0f}" for n, x in zip(names, v)) + f"  total {v.sum() / nw:.0f}  ({int(nw)} wave-cells)")
