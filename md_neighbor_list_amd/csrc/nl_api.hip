@@ -77,8 +77,13 @@ struct nl_handle_s {
   void* resort_buf = nullptr;      // scratch of nl_resort (32 bytes per particle), allocated on first use
   int64_t rstride = 0;
   bool b_half = false;             // this build: half-shell search
+  int32_t b_mask_nb = 1;           // this build: mask rows per sorted slot (> 1: dense build, k_fill_dense)
+  size_t masks_bytes = 0;          // size of the masks allocation
   int32_t b_isplit = 1;            // this build, two-sweep path: workgroups per cell
   int isplit_env = 0;              // NL_ISPLIT: 0 = by density
+  bool dense_masks_off = false;    // NL_DENSE_MASKS=0: dense builds use two distance sweeps (the round-1 path)
+  size_t dense_masks_limit = (size_t)64 << 30;  // most memory the mask rows of a dense build may take
+  bool pending_alloc_ok = true;
   int half_cpb = 4;                // cells a workgroup of k_sweep_half walks (NL_HALF_CPB)
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps;
                                    // 3 (default): COUNT keeping hit masks + mask expansion
@@ -261,6 +266,7 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.masks = h->masks;
   a.fmask = h->fmask, a.rmask = h->rmask, a.fcnt = h->fcnt, a.rcnt = h->rcnt, a.rstride = h->rstride;
   a.isplit = 1, a.cells_per_block = 1, a.ncells_grid = 0;
+  a.mask_nb = h->b_mask_nb;
   a.full27_list = h->full27_list;
   a.full27_count = reinterpret_cast<int32_t*>(h->status) + META_FULL27;
   a.pbc = h->pbc ? 1 : 0;
@@ -277,6 +283,11 @@ template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(
   if (h->n > 0)
     hipLaunchKernelGGL(k_row_base<OFF>, dim3(nbp), dim3(256), 0, s, static_cast<const OFF*>(h->key_pointer), h->sorted_row,
                        h->n_rows, h->n, static_cast<OFF*>(h->base_sorted));
+  if (h->b_mask_nb > 1) {  // dense build: mask rows per (slot, LDS batch)
+    hipLaunchKernelGGL((k_fill_dense<T, FULL, PBC, OFF>), dim3(ncells_i), dim3(FD_WAVES * WAVE), 0, s, a,
+                       static_cast<const OFF*>(h->base_sorted));
+    return;
+  }
   hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
                      static_cast<const OFF*>(h->base_sorted));
 }
@@ -328,7 +339,7 @@ template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h,
     }
     return;
   }
-  // two distance sweeps.  Dense cells are shared by several workgroups (sweep_cell): about 64 i-particles each
+  // two distance sweeps
   SweepArgs<T> a2 = a;
   a2.isplit = h->b_isplit;
   const int32_t grid2 = ncells_i * h->b_isplit;
@@ -370,15 +381,27 @@ void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int
   h->b_variant = h->sweep_variant;
   // Hit masks pay off while a cell's stencil fits one LDS batch; where the mean stencil (27 cells) is close to or
   // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
-  const bool sparse_enough = 27.0 * n <= 0.85 * SweepCfg<T>::CAP * (double)ncl;  // mean stencil <= 1088: <= 40.3 per cell
+  const double mean_stream = ncl > 0 ? 27.0 * n / (double)ncl : 0.0;
+  const bool sparse_enough = mean_stream <= 0.85 * SweepCfg<T>::CAP;  // mean stencil <= 1088: <= 40.3 per cell
   h->b_half = h->b_variant >= 5 && h->fmask && sparse_enough;
   h->b_use_masks = h->b_variant >= 3 && h->b_variant < 5 && h->masks && sparse_enough;
+  h->b_mask_nb = 1;
+  if (h->b_variant >= 3 && !sparse_enough && !h->dense_masks_off) {
+    // Dense cells: hit masks for up to FD_NB LDS batches per slot instead of a second distance sweep, when the streams
+    // (mean + 5 sigma of a Poisson count) fit that many batches and the mask rows fit the memory set aside for them
+    const int64_t nb = (int64_t)((mean_stream + 5.0 * std::sqrt(mean_stream) + 64.0) / SweepCfg<T>::CAP) + 1;
+    const size_t need = (size_t)MASK_ROW_BYTES * (size_t)nb * ((size_t)h->n_max + 16);
+    if (nb <= FD_NB && need <= h->dense_masks_limit) {
+      if (need > h->masks_bytes) {  // (synchronous allocation: first dense build of the handle only)
+        if (h->pending_alloc_ok && dev_alloc(h, &h->masks, need) == NL_OK) h->masks_bytes = need;
+      }
+      if (need <= h->masks_bytes && h->masks) h->b_use_masks = true, h->b_mask_nb = (int32_t)nb;
+    }
+  }
   // 64-bit list offsets as soon as the list this handle can hold exceeds what an int32 key_pointer can address
   // (the reference's own limit, neighlist_cpu.hpp:15,29); nl_set_offset_width overrides.
-  {  // dense cells: one workgroup per ~64 i-particles of a cell (two-sweep path only)
-    const double per_cell = ncl > 0 ? (double)n / (double)ncl : 0.0;
-    int32_t sp = h->isplit_env > 0 ? h->isplit_env : (int32_t)(per_cell / 64.0 + 0.5);
-    sp = std::max(1, std::min(sp, 32));
+  {  // NL_ISPLIT (diagnostics): workgroups per cell in the two-sweep path; default 1 (see sweep_cell)
+    int32_t sp = std::max(1, std::min(h->isplit_env, 32));
     if ((int64_t)sp * ncl > 2000000000LL) sp = 1;
     h->b_isplit = (h->b_use_masks || h->b_half) ? 1 : sp;
   }
@@ -734,6 +757,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : atoi(v) >= 6 ? 6 : atoi(v) == 5 ? 5 : 3;
     if (const char* v = getenv("NL_ISPLIT")) h->isplit_env = std::max(0, atoi(v));
+    if (const char* v = getenv("NL_DENSE_MASKS")) h->dense_masks_off = atoi(v) == 0;
     if (const char* v = getenv("NL_HALF_CPB")) h->half_cpb = std::max(1, atoi(v));
     if (const char* v = getenv("NL_OFFSET_WIDTH")) h->offset_width = atoi(v) == 64 ? 64 : atoi(v) == 32 ? 32 : 0;
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
@@ -799,7 +823,10 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
     if ((rc = dev_alloc(h, &h->tmp_pos, pos_bytes * (n + 16)))) return rc;
     if ((rc = dev_alloc(h, &h->tmp_row, 4 * (n + 16)))) return rc;
   }
-  if (h->sweep_variant >= 3 && h->sweep_variant < 5 && (rc = dev_alloc(h, &h->masks, (size_t)MASK_ROW_BYTES * (n + 16)))) return rc;
+  if (h->sweep_variant >= 3 && h->sweep_variant < 5) {
+    if ((rc = dev_alloc(h, &h->masks, (size_t)MASK_ROW_BYTES * (n + 16)))) return rc;
+    h->masks_bytes = (size_t)MASK_ROW_BYTES * (n + 16);
+  }
   if (h->sweep_variant >= 5) {
     h->rstride = (int64_t)((n + 64 + 63) / 64 * 64);
     if ((rc = dev_alloc(h, &h->fmask, 2 * (size_t)WAVE * (n + 16)))) return rc;
@@ -933,6 +960,10 @@ int make_list_slab_part(nl_handle_t h, const void* q_dev, int32_t q_stride, cons
     if (!h->graph_exec || !(key == h->graph_key)) {
       if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec), h->graph_exec = nullptr;
       if (h->graph) (void)hipGraphDestroy(h->graph), h->graph = nullptr;
+      // (whatever the build has to allocate -- the mask rows of a first dense build -- is allocated before the capture)
+      if (h->dtype == NL_F32) set_build_state<float>(h, q_dev, q_stride, gid_dev, n, z_lo, mzl, slab);
+      else set_build_state<double>(h, q_dev, q_stride, gid_dev, n, z_lo, mzl, slab);
+      key.epoch = h->buffers_epoch;
       // captured on the private stream (the null stream cannot be captured); replayed on the caller's stream
       HIPCHK(h, hipStreamBeginCapture(h->own_stream, hipStreamCaptureModeRelaxed));
       rc = dispatch_build(h, q_dev, q_stride, gid_dev, n_rows, n, z_lo, mzl, slab, h->own_stream, nullptr);

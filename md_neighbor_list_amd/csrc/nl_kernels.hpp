@@ -633,6 +633,7 @@ template <typename T> struct SweepArgs {
   int64_t rstride;
   int32_t cells_per_block, ncells_grid;    // k_sweep_half / k_fill_half: cells a workgroup walks, cells of the launch
   int32_t isplit;                          // two-sweep path: workgroups per cell (each a part of the cell's i-particles)
+  int32_t mask_nb;                         // mask rows per sorted slot: 1, or up to FD_NB LDS batches in a dense build
   int32_t* __restrict__ full27_list;       // local cell indices of the cells k_full27 builds (irregular stencil)
   int32_t* __restrict__ full27_count;      // their number: a meta word next to the status word, zeroed with it
   uint32_t* __restrict__ masks;  // [n] rows of 64 x 24 bits (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
@@ -676,7 +677,7 @@ constexpr int NSEG = 18;
 template <typename T, int MODE, int GC, bool FULL = false, bool NOSELF = false>
 __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos<T>* tile, int32_t nj,
                                                 int32_t ntiles, int lane, const Pos<T>& pi_l, int64_t base_l,
-                                                int32_t slot0 = 0, bool store_masks = false, int32_t self0 = 0) {
+                                                int32_t slot0 = 0, bool store_masks = false, int32_t self0 = 0, int32_t batch = 0) {
   static_assert(!NOSELF || (FULL && MODE == MODE_COUNT_MASKS), "NOSELF is a form of the full-list COUNT_MASKS search");
   static_assert(SweepCfg<T>::CAP / WAVE <= 24, "one bit per j-tile in the 24-bit word a lane keeps (mask_store)");
   T xi[GC], yi[GC], zi[GC];
@@ -763,7 +764,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
       for (int k = 0; k < GC; k++) {
         uint32_t w = __brev(bits[k]) >> (32 - ntiles);
         if (NOSELF && lane == ((self0 + k) & (WAVE - 1))) w &= ~(1u << ((self0 + k) >> 6));
-        mask_store(a.masks, (size_t)(slot0 + k), lane, w);
+        mask_store(a.masks, (size_t)(slot0 + k) * a.mask_nb + batch, lane, w);  // mask row of (slot, LDS batch)
       }
     }
     if (NOSELF) {
@@ -941,7 +942,9 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       }
       const int32_t slot0 = ibeg + i0;
       // hit masks are kept only for single-batch cells (k_fill_masks re-searches the rest)
-      const bool keep = nbatch == 1 && CAP == SweepCfg<T>::CAP;
+      // hit masks are kept for cells whose stencil fits the mask rows the build provides per slot: one LDS batch in the
+      // usual regime, up to FD_NB in a dense build (k_fill_dense); the expansion kernels re-search the rest
+      const bool keep = nbatch <= a.mask_nb && CAP == SweepCfg<T>::CAP;
       int32_t mine;  // lane k < gcount: hits of i-particle k in this batch
       if constexpr (CAN_NOSELF) {
         if (nbatch == 1) {  // (uniform) the row's own particle is in this, the only, batch
@@ -957,11 +960,11 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
         }
       }
       switch (gcount) {
-        case 1: mine = search_group<T, MODE, 1, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        case 2: mine = search_group<T, MODE, 2, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        case 3: mine = search_group<T, MODE, 3, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        case 4: mine = search_group<T, MODE, 4, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
-        default: mine = search_group<T, MODE, 5, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep); break;
+        case 1: mine = search_group<T, MODE, 1, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
+        case 2: mine = search_group<T, MODE, 2, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
+        case 3: mine = search_group<T, MODE, 3, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
+        case 4: mine = search_group<T, MODE, 4, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
+        default: mine = search_group<T, MODE, 5, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
       }
       if (lane < gcount) {
         if (nbatch > 1) {
@@ -975,12 +978,10 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
   }
 }
 
-// LDS batch of the sweeps.  The two distance sweeps of fp64 builds (dense cells: BASELINE config 5) take half the batch:
-// 20 KB instead of 40 KB per workgroup, so that registers (5-6 waves per SIMD), not LDS (4), bound their occupancy;
-// a staged particle is tested against ~60 i-particles there, so twice the staging steps cost little.
-template <typename T, int MODE> constexpr int sweep_cap() {
-  return sizeof(T) == 8 && MODE != MODE_COUNT_MASKS ? SweepCfg<T>::CAP / 2 : SweepCfg<T>::CAP;
-}
+// LDS batch of the sweeps.  (Measured at BASELINE config 5, fp64, 311 particles per cell: half the batch -- 20 KB of
+// LDS per workgroup instead of 40, 5-6 resident waves per SIMD instead of 4 -- is 10 % SLOWER, 8.54 against 7.77 ms:
+// the dense sweeps are bound by the fp64 vector rate, and every batch costs a staging step and two barriers.)
+template <typename T, int MODE> constexpr int sweep_cap() { return SweepCfg<T>::CAP; }
 
 template <typename T, int MODE, bool FULL = false, bool PBC = false>
 __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
@@ -997,9 +998,10 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   if (MODE == MODE_COUNT_MASKS || a.isplit <= 1) {
     if (!cell_setup(a, lane, c)) return;
   } else {
-    // Dense cells (hundreds of particles: 2 x cut-off) are shared by a.isplit workgroups, each taking a contiguous part
-    // of the cell's i-particles against the whole stream: a box of a few thousand cells otherwise leaves the last
-    // quarter of the chip idle behind a handful of 2 ms workgroups.  Parts of a cell are neighbours in the XCD order.
+    // NL_ISPLIT = S > 1 (diagnostics): a cell is shared by S workgroups, each taking a contiguous part of the cell's
+    // i-particles against the whole stream.  Meant for boxes of a few thousand dense cells (BASELINE config 5: 3375
+    // workgroups of ~2 ms on 1024 slots); measured: S = 3 -3 %, S = 5 +3 %, S = 8 +11 % -- every part stages the whole
+    // stream again -- so the default stays one workgroup per cell.
     const int32_t wp = xcd_cell_index(), w = wp / a.isplit, part = wp - w * a.isplit;
     const int32_t wy = (int32_t)fastdiv((uint32_t)w, a.div_mx), cx = w - wy * a.mx;
     const int32_t wz = (int32_t)fastdiv((uint32_t)wy, a.div_my), cy = wy - wz * a.my, cz = wz + (a.slab ? 1 : 0);
@@ -1092,7 +1094,7 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const int32_t slot = c.ibeg + min(r0 + u, c.ni - 1);
-      w[u] = mask_load(a.masks, (size_t)slot, lane);
+      w[u] = mask_load(a.masks, (size_t)slot * a.mask_nb, lane);
       base[u] = base_sorted[slot];  // (k_row_base: one gather kernel is cheaper than two dependent loads here)
     }
   };
@@ -1193,6 +1195,130 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
           }
         }
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------- list from masks, dense cells
+// The expansion for builds whose cells hold hundreds of particles (2 x cut-off, BASELINE config 5: 311 per cell, a
+// stencil stream of 8400): COUNT_MASKS kept one mask row per (slot, LDS batch), up to FD_NB batches.  One workgroup per
+// cell stages the ids of the WHOLE stream (40 KB of LDS), then every wave walks its rows two at a time: the popcounts of
+// the row's words give every lane its place (one DPP scan), and the lanes put their set bits of batch b, tile t --
+// staged particle b * CAP + t * 64 + lane -- straight into the row (the bit loops run with most lanes live here: ~9 set
+// bits per lane and row).  Replaces the second distance sweep (k_sweep<FILL>: 4.4 of the 7.8 ms of a config-5 build).
+// Cells whose stream needs more than a.mask_nb batches carry no masks and are searched again, as in k_fill_masks.
+constexpr int FD_NB = 7;       // LDS batches of ids a workgroup holds: 35 KB
+constexpr int FD_WAVES = 4;
+constexpr int FD_RMAX = 1024;  // longest row assembled in LDS (4 KB per wave); longer rows go entry by entry
+
+template <typename T, bool FULL = false, bool PBC = false, typename OFF = int32_t>
+__global__ void __launch_bounds__(FD_WAVES* WAVE) k_fill_dense(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
+  constexpr int CAP = SweepCfg<T>::CAP;
+  __shared__ __attribute__((aligned(32))) int32_t lds[FD_NB * CAP + FD_WAVES * FD_RMAX];
+  int32_t* const gids = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t total = a.total[0];
+  CellCtx c;
+  const bool ok = cell_setup(a, lane, c);
+  if (total > a.capacity) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
+    return;
+  }
+  if (!ok) return;
+  const int32_t nbatch = (c.total_j + CAP - 1) / CAP;
+  if (nbatch > a.mask_nb) {  // no masks for this cell: search it again through the same LDS
+    constexpr int CAPS = (int)(FD_NB * CAP * sizeof(int32_t) / sizeof(Pos<T>)) / WAVE * WAVE;
+    cell_search<T, MODE_FILL, CAPS, FD_WAVES, FULL, PBC>(a, c, reinterpret_cast<Pos<T>*>(gids), tid, lane, wave);
+    return;
+  }
+  const int32_t nb = a.mask_nb;
+  constexpr int FD_RB = 4;
+  // Every load of a batch of rows is issued before the first of them is waited for: a load under a branch (the compiler
+  // turns "b < nbatch ? load : 0" into one, the condition being uniform) is waited for at the join, one memory round
+  // trip per word -- 28 per batch in the first cut, 74 % of the wave cycles in s_waitcnt.  Hence: unconditional loads
+  // of valid rows, an empty asm that takes every loaded value (the loads cannot sink under a branch), then the selects.
+  auto load_rows = [&](int32_t r0, uint32_t (&w)[FD_RB][FD_NB], OFF (&base)[FD_RB]) {
+#pragma unroll
+    for (int u = 0; u < FD_RB; u++) {
+      const int32_t slot = c.ibeg + min(r0 + u * FD_WAVES, c.ni - 1);
+      base[u] = base_sorted[slot];
+#pragma unroll
+      for (int b = 0; b < FD_NB; b++) w[u][b] = mask_load(a.masks, (size_t)slot * nb + min(b, nb - 1), lane);
+    }
+#pragma unroll
+    for (int u = 0; u < FD_RB; u++)
+#pragma unroll
+      for (int b = 0; b < FD_NB; b++) asm volatile("" : "+v"(w[u][b]));
+#pragma unroll
+    for (int u = 0; u < FD_RB; u++)
+#pragma unroll
+      for (int b = 0; b < FD_NB; b++) w[u][b] = (b < nbatch && r0 + u * FD_WAVES < c.ni) ? (w[u][b] & 0xFFFFFFu) : 0u;
+  };
+  // A wave's rows come in register batches of FD_RB: all their words are loaded before the first store of the batch
+  // (vmcnt retires in order, so a load issued behind stores waits for every one of them: with one row prefetched per
+  // row the kernel spent 74 % of its wave cycles in s_waitcnt -- profiles/r02_v2_cfg5_dense_fill_first_cut_pmc.txt).
+  uint32_t wb[FD_RB][FD_NB];
+  OFF baseb[FD_RB];
+  // ids of the whole stream, LDS-DMA (see k_fill_masks)
+  for (int32_t sg = wave; sg < NSEG; sg += FD_WAVES) {
+    const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
+    const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
+    const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg);
+    for (int32_t kb = 0; kb < len; kb += WAVE) {
+      if (kb + lane < len)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.sorted_gid + src + kb + lane),
+                                         (__attribute__((address_space(3))) void*)(gids + off + kb), 4, 0, 0);
+    }
+  }
+  __syncthreads();
+  const int32_t* const g = gids + lane;
+  int32_t* const cw = lds + FD_NB * CAP + wave * FD_RMAX;
+  for (int32_t rb = wave; rb < c.ni; rb += FD_WAVES * FD_RB) {
+    load_rows(rb, wb, baseb);
+#pragma unroll
+    for (int u = 0; u < FD_RB; u++) {
+    const int32_t r = rb + u * FD_WAVES;
+    if (r >= c.ni) break;  // uniform
+    uint32_t (&wd)[FD_NB] = wb[u];
+    const OFF base = baseb[u];
+    int32_t cnt = 0;
+#pragma unroll
+    for (int b = 0; b < FD_NB; b++) cnt += __popc(wd[b]);
+    const int32_t incl = scan64_dpp(cnt);
+    const int32_t nrow = __builtin_amdgcn_readlane(incl, 63);
+    uint32_t ptr = (uint32_t)(incl - cnt);
+    const bool in_lds = nrow <= FD_RMAX;  // uniform
+    // two batches' words at a time: two independent chains of LDS read -> write per trip
+#pragma unroll
+    for (int b = 0; b < FD_NB; b += 2) {
+      if (b >= nbatch) break;  // uniform
+      uint32_t w0 = wd[b], w1 = b + 1 < FD_NB ? wd[b + 1] : 0u;
+      const int32_t* const g0 = g + b * CAP;
+      const int32_t* const g1 = g + (b + 1 < FD_NB ? b + 1 : b) * CAP;
+      // (entries of batch b come before those of b + 1 inside a lane's run: the run's order is free, its extent is not)
+      uint32_t p0 = ptr, p1 = ptr + (uint32_t)__popc(w0);
+      ptr = p1 + (uint32_t)__popc(w1);
+      while (__builtin_amdgcn_ballot_w64((w0 | w1) != 0)) {
+        const bool on0 = w0 != 0, on1 = w1 != 0;
+        const int32_t v0 = g0[(on0 ? __ffs(w0) - 1 : 0) * WAVE];
+        const int32_t v1 = g1[(on1 ? __ffs(w1) - 1 : 0) * WAVE];
+        if (on0) {
+          if (in_lds) cw[p0] = v0;
+          else a.list[(size_t)base + p0] = v0;
+          p0++, w0 &= w0 - 1;
+        }
+        if (on1) {
+          if (in_lds) cw[p1] = v1;
+          else a.list[(size_t)base + p1] = v1;
+          p1++, w1 &= w1 - 1;
+        }
+      }
+    }
+    if (in_lds) {
+      __builtin_amdgcn_wave_barrier();  // the buffer is private to the wave: LDS executes its accesses in order
+      for (int32_t e = lane; e < nrow; e += WAVE) a.list[(size_t)base + e] = cw[e];
+      __builtin_amdgcn_wave_barrier();
+    }
     }
   }
 }
