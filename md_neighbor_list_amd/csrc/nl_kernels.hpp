@@ -883,6 +883,10 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
     // ---- stage: copy the stream window [win0, win0 + nj) into LDS.  The waves share the segments (slot s goes
     // to wave s mod 4: the nine never-empty slots spread 3/2/2/2); a wave copies a segment 128 particles at a
     // time with both 16-byte loads in flight before the LDS writes.
+    // (Measured twice and slower both times -- round 1 with LDS-DMA, round 2 with all of a wave's 16-byte loads forced
+    // into flight before the first LDS write, 355 against 340 us at cfg 2 and 273 against 254 at cfg 3: in the loop below
+    // the compiler waits for every load before it issues the next, 4-6 dependent round trips per wave and cell, and the
+    // kernel is the faster for it.  profiles/r02_count_staging_ab.txt)
     for (int32_t sg = wave; sg < NSEG; sg += NW) {
       const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
       if (len == 0) continue;
