@@ -204,6 +204,7 @@ template <typename T> Grid<T> make_grid(nl_handle_t h, int32_t n_rows, int32_t z
   g.z_origin = slab ? ((z_lo - 1) % h->m[2] + h->m[2]) % h->m[2] : 0;
   g.n_rows = n_rows;
   g.pbc = h->pbc ? 1 : 0;
+  g.dbg = h->dbg_flags;
   g.z_first = slab ? z_lo - 1 : 0;
   for (int d = 0; d < 3; d++) g.L[d] = (T)h->L[d];
   return g;

@@ -44,6 +44,7 @@ template <typename T> struct Grid {
   int32_t slab;      // 0: periodic wrap in z, every cell owned; 1: layers 0 and mzl-1 are ghosts
   int32_t n_rows;    // particles [0, n_rows) are owned (get rows), [n_rows, n) are ghosts
   // minimum-image mode (nl_set_periodic; not in the reference, which wraps cells but never distances):
+  int32_t dbg;       // diagnostics (NL_DEBUG_FLAGS): 512 = binning kernels without the keep_in_flight of their loads
   int32_t pbc;       // 1: a particle whose cell index was wrapped (or that sits in a slab's wrapped ghost layer) is
                      //    stored at its periodic image next to that cell: coordinate -+ L
   int32_t z_first;   // slab: global layer that local layer 0 stands for, z_lo - 1 (may be -1)
@@ -93,6 +94,12 @@ __device__ __forceinline__ int32_t local_cell(const Grid<T>& g, T x, T y, T z, i
   if (row_out) *row_out = idx[1] + lz * g.m[1];  // the row of x-cells the particle lies in
   return idx[0] + (idx[1] + lz * g.m[1]) * g.m[0];
 }
+
+// Takes loaded values in an empty asm: whatever was loaded before it is in flight together.  The scheduler, left alone,
+// keeps few registers live and waits for every load before it issues the next (one memory round trip per load).
+__device__ __forceinline__ void keep_in_flight(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void keep_in_flight(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void keep_in_flight(int32_t& v) { asm volatile("" : "+v"(v)); }
 
 template <typename T>
 __device__ __forceinline__ void load_xyz(const T* __restrict__ q, int32_t stride, int32_t i, T& x, T& y, T& z) {
@@ -414,6 +421,10 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_rows(const T* __restrict__ 
     T x[BIN_UNROLL], y[BIN_UNROLL], z[BIN_UNROLL];
 #pragma unroll
     for (int u = 0; u < BIN_UNROLL; u++) load_xyz(q, stride, min(i0 + u * BIN_THREADS, end - 1), x[u], y[u], z[u]);
+    if (!(g.dbg & 512)) {
+#pragma unroll
+      for (int u = 0; u < BIN_UNROLL; u++) keep_in_flight(x[u]), keep_in_flight(y[u]), keep_in_flight(z[u]);
+    }
 #pragma unroll
     for (int u = 0; u < BIN_UNROLL; u++) {
       const int32_t i = i0 + u * BIN_THREADS;
@@ -485,16 +496,34 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
   for (int32_t i0 = beg + tid; i0 < end; i0 += BIN_UNROLL * BIN_THREADS) {  // all loads of a trip first (see k_bin_rows)
     T x[BIN_UNROLL], y[BIN_UNROLL], z[BIN_UNROLL];
     int32_t id[BIN_UNROLL];
+    // three loops, one per id source, each free of branches between its loads: a load under a branch is waited for at
+    // the join (one memory round trip per particle instead of one per trip)
+    if (gid_in_w) {
 #pragma unroll
-    for (int u = 0; u < BIN_UNROLL; u++) {
-      const int32_t i = min(i0 + u * BIN_THREADS, end - 1);
-      load_xyz(q, stride, i, x[u], y[u], z[u]);
-      if (gid_in_w) {
+      for (int u = 0; u < BIN_UNROLL; u++) {
+        const int32_t i = min(i0 + u * BIN_THREADS, end - 1);
+        load_xyz(q, stride, i, x[u], y[u], z[u]);
         if constexpr (sizeof(T) == 4) id[u] = __float_as_int(q[(size_t)i * 4 + 3]);
         else id[u] = (int32_t)__double_as_longlong(q[(size_t)i * 4 + 3]);
-      } else {
-        id[u] = gid ? gid[i] : i;
       }
+    } else if (gid) {
+#pragma unroll
+      for (int u = 0; u < BIN_UNROLL; u++) {
+        const int32_t i = min(i0 + u * BIN_THREADS, end - 1);
+        load_xyz(q, stride, i, x[u], y[u], z[u]);
+        id[u] = gid[i];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < BIN_UNROLL; u++) {
+        const int32_t i = min(i0 + u * BIN_THREADS, end - 1);
+        load_xyz(q, stride, i, x[u], y[u], z[u]);
+        id[u] = i;
+      }
+    }
+    if (!(g.dbg & 512)) {
+#pragma unroll
+      for (int u = 0; u < BIN_UNROLL; u++) keep_in_flight(x[u]), keep_in_flight(y[u]), keep_in_flight(z[u]), keep_in_flight(id[u]);
     }
 #pragma unroll
     for (int u = 0; u < BIN_UNROLL; u++) {
@@ -542,7 +571,30 @@ __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, con
     if (v >= mx) v -= mx;
     return v;
   };
-  for (int32_t k = beg + tid; k < end; k += 256) atomicAdd(&cnt[xcell(tmp[k].x)], 1);
+  // The row's particles stay in registers between the histogram and the placement (rows of up to BC_KEEP * 256: one
+  // read of tmp instead of two, and all of a thread's loads in one round trip); longer rows are read twice.
+  constexpr int BC_KEEP = 6;
+  const bool keep = end - beg <= BC_KEEP * 256 && end > beg && !(g.dbg & 512);
+  Pos<T> pk[BC_KEEP];
+  int32_t rk[BC_KEEP];
+  if (keep) {
+#pragma unroll
+    for (int u = 0; u < BC_KEEP; u++) {
+      const int32_t k = min(beg + tid + u * 256, end - 1);
+      pk[u] = tmp[k];
+      rk[u] = tmp_row[k];
+    }
+#pragma unroll
+    for (int u = 0; u < BC_KEEP; u++) {
+      keep_in_flight(pk[u].x), keep_in_flight(pk[u].y), keep_in_flight(pk[u].z), keep_in_flight(pk[u].gid), keep_in_flight(rk[u]);
+      if constexpr (sizeof(T) == 8) keep_in_flight(pk[u].row);
+    }
+#pragma unroll
+    for (int u = 0; u < BC_KEEP; u++)
+      if (beg + tid + u * 256 < end) atomicAdd(&cnt[xcell(pk[u].x)], 1);
+  } else {
+    for (int32_t k = beg + tid; k < end; k += 256) atomicAdd(&cnt[xcell(tmp[k].x)], 1);
+  }
   __syncthreads();
   // exclusive scan of cnt[0..mx) in place, 256 entries at a time, and the row's slice of cell_start
   for (int32_t base = 0; base < mx; base += 256) {
@@ -564,8 +616,7 @@ __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, con
     __syncthreads();
   }
   if (r == nrows - 1 && tid == 0) cell_start[(size_t)nrows * mx] = end;
-  for (int32_t k = beg + tid; k < end; k += 256) {
-    Pos<T> p = tmp[k];
+  auto place = [&](Pos<T> p, int32_t row_of) {
     const int32_t dst = beg + atomicAdd(&cnt[xcell(p.x)], 1);
     if (g.pbc) {  // minimum-image mode: a wrapped x index means the particle is stored at its image
       const T tx = mul_rn(p.x, g.ims[0]);
@@ -575,8 +626,15 @@ __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, con
       if (v >= mx) p.x = add_rn(p.x, -g.L[0]);
     }
     sorted[dst] = p;
-    sorted_row[dst] = tmp_row[k];
+    sorted_row[dst] = row_of;
     sorted_gid[dst] = p.gid;  // the ids alone, 4 bytes apart: what the expansion kernel stages
+  };
+  if (keep) {
+#pragma unroll
+    for (int u = 0; u < BC_KEEP; u++)
+      if (beg + tid + u * 256 < end) place(pk[u], rk[u]);
+  } else {
+    for (int32_t k = beg + tid; k < end; k += 256) place(tmp[k], tmp_row[k]);
   }
 }
 
