@@ -271,6 +271,7 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.full27_list = h->full27_list;
   a.full27_count = reinterpret_cast<int32_t*>(h->status) + META_FULL27;
   a.pbc = h->pbc ? 1 : 0;
+  for (int d = 0; d < 3; d++) a.ms[d] = (T)(h->L[d] / h->m[d]);
   for (int d = 0; d < 3; d++) a.L[d] = (T)h->L[d];
   a.z_origin = h->b_slab ? h->b_zlo - 1 : 0;
   a.dbg = h->dbg_flags;

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace nl {
 
 constexpr int WAVE = 64;
@@ -682,6 +684,7 @@ template <typename T> struct SweepArgs {
   T L[3];                         // box lengths rounded to T (minimum-image mode)
   int32_t pbc;                    // minimum-image mode: stencil cells reached through the periodic wrap are staged
                                   // at their image, coordinate -+ L (nl_set_periodic; not in the reference)
+  T ms[3];                        // cell edge (screened fp64 search: origin of the relative coordinates)
   int32_t z_origin;               // global z layer of local layer 0
   // half-shell search (nl_half.hpp)
   uint16_t* __restrict__ fmask;            // [n][64] F words: bit t of lane l of a slot = staged particle t*64 + l accepted
@@ -722,6 +725,26 @@ constexpr int SWEEP_WAVES = 4;
 constexpr int SWEEP_G = 5;
 constexpr int NSEG = 18;
 
+// ---- screened fp64 search.  The fp64 vector rate of the chip is half its fp32 rate, and the fp64 distance test is what
+// bounds the fp64 builds (BASELINE config 5).  The fp64 sweeps therefore stage the stream as FLOATS RELATIVE TO THE
+// CENTRE OF THE i-CELL, decide every pair whose fp32 r2 lies outside a band around rc2 in fp32, and evaluate only the
+// pairs inside the band (a few in a million) with the reference's exact fp64 expression on the original coordinates:
+// the accepted set is the reference's, bit for bit.  Band: with u = x - centre, A_c = |u_j,c| + |u_i,c|, the fp32 value
+// differs from the exact sum of squares by at most (4.02 + 3) 2^-24 sum_c A_c^2 <= 7.1 2^-24 (L1(u_j) + L1(u_i))^2
+// (rounding of u to float, of the difference, of the three products / FMAs); the kernels use 16 2^-24 (R_i + R_j)^2 with
+// R the largest L1 norm of the group's i-particles / of the staged batch, plus 4 2^-24 rc2 for the rounding of rc2.
+struct alignas(16) PosS {
+  float x, y, z;
+  int32_t gid;
+};
+struct ScreenCtx {
+  float lo, hi;               // r2f < lo: in range; r2f > hi: out of range; else exact test
+  const int32_t* sidx;        // [batch slots] sorted-array index of every staged particle (exact coordinates)
+  const uint8_t* swrap;       // [batch slots] periodic-face code of its segment (minimum-image mode)
+};
+template <typename T, bool SCREEN> struct TileOf { typedef Pos<T> type; };
+template <typename T> struct TileOf<T, true> { typedef PosS type; };
+
 // One group of GC (compile-time, 1..5) i-particles against the nj staged j-particles.
 // pi_l / base_l: lane k < GC holds i-particle k and the list offset of its row.  Returns, in lane k, the number
 // of accepted partners of i-particle k.  All per-i state is wave-uniform (SGPRs): position, id, running count.
@@ -732,13 +755,17 @@ constexpr int NSEG = 18;
 // NOSELF (full list, COUNT_MASKS, the whole stream in one batch): "every j != i in range" is tested as "every j in
 // range" -- no id compare and no s_and per test -- and the row's own particle (distance 0: always in range), staged at
 // stream position self0 + k, is taken out of the word and of the count once at the end.
-template <typename T, int MODE, int GC, bool FULL = false, bool NOSELF = false>
-__device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos<T>* tile, int32_t nj,
+template <typename T, int MODE, int GC, bool FULL = false, bool NOSELF = false, bool SCREEN = false, bool PBC = false>
+__device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typename TileOf<T, SCREEN>::type* tile, int32_t nj,
                                                 int32_t ntiles, int lane, const Pos<T>& pi_l, int64_t base_l,
-                                                int32_t slot0 = 0, bool store_masks = false, int32_t self0 = 0, int32_t batch = 0) {
+                                                int32_t slot0 = 0, bool store_masks = false, int32_t self0 = 0, int32_t batch = 0,
+                                                const ScreenCtx* sc = nullptr, float uxi_l = 0.f, float uyi_l = 0.f, float uzi_l = 0.f) {
   static_assert(!NOSELF || (FULL && MODE == MODE_COUNT_MASKS), "NOSELF is a form of the full-list COUNT_MASKS search");
   static_assert(SweepCfg<T>::CAP / WAVE <= 24, "one bit per j-tile in the 24-bit word a lane keeps (mask_store)");
-  T xi[GC], yi[GC], zi[GC];
+  static_assert(!SCREEN || sizeof(T) == 8, "the screened search is the fp64 search");
+  typedef typename TileOf<T, SCREEN>::type TileT;
+  typedef typename std::conditional<SCREEN, float, T>::type R;  // type of the coordinates the hot loop works in
+  R xi[GC], yi[GC], zi[GC];
   int32_t gi[GC];
   uint32_t cur[GC];  // hits so far
   int32_t* rowp[GC];  // FILL: where the row's next entry goes (wave-uniform 64-bit pointer: the list may exceed 2^31 entries)
@@ -747,7 +774,11 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   for (int k = 0; k < GC; k++) bits[k] = 0;
 #pragma unroll
   for (int k = 0; k < GC; k++) {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (SCREEN) {
+      xi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, uxi_l), k));
+      yi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, uyi_l), k));
+      zi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, uzi_l), k));
+    } else if constexpr (sizeof(T) == 4) {
       xi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, pi_l.x), k));
       yi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, pi_l.y), k));
       zi[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, pi_l.z), k));
@@ -768,18 +799,62 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   // One tile of 64 staged j-particles (lanes) against the GC i-particles (SGPRs).  All vector work of the GC
   // tests comes first (masks land in SGPR pairs), the scalar bookkeeping afterwards: a scalar instruction that
   // consumes a v_cmp result stalls the wave until the compare has left the VALU.
-  auto test_tile = [&](const Pos<T>& pj, int32_t tix) {
+  auto test_tile = [&](const TileT& pj, int32_t tix) {
     uint64_t mask[GC];
     bool hit[GC];  // per-lane predicate: lives in an SGPR pair as a lane mask, costs no VALU
+    if constexpr (SCREEN) {
+      // fp32 screening of the GC tests of this tile, ONE branch for all of them (a branch per test would put a
+      // VALU -> SALU -> branch dependency between the tests)
+      uint64_t m_in[GC], m_unc[GC], any_unc = 0;
 #pragma unroll
-    for (int k = 0; k < GC; k++) {
-      const T dx = sub_rn(pj.x, xi[k]), dy = sub_rn(pj.y, yi[k]), dz = sub_rn(pj.z, zi[k]);
-      const T r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
-      // half list: j is kept by the particle with the smaller id; full list: everyone but i itself
-      const bool in_range = !(r2 > a.rc2), upper = NOSELF ? true : FULL ? pj.gid != gi[k] : pj.gid > gi[k];
-      hit[k] = in_range && upper;
-      mask[k] = NOSELF ? __builtin_amdgcn_ballot_w64(in_range)
-                       : __builtin_amdgcn_ballot_w64(in_range) & __builtin_amdgcn_ballot_w64(upper);
+      for (int k = 0; k < GC; k++) {
+        const float dx = pj.x - xi[k], dy = pj.y - yi[k], dz = pj.z - zi[k];
+        const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        m_in[k] = __builtin_amdgcn_ballot_w64(r2 < sc->lo);
+        m_unc[k] = ~(m_in[k] | __builtin_amdgcn_ballot_w64(r2 > sc->hi));  // two compares per test; a NaN is "uncertain"
+        any_unc |= m_unc[k];
+      }
+      if (any_unc) {  // (uniform, rare) some pair is inside the band: the reference's expression on the original coordinates
+        const int32_t at = tix * WAVE + lane;
+        Pos<double> pe;
+        pe.x = 0, pe.y = 0, pe.z = 0;
+        if ((any_unc >> lane) & 1ull) {
+          pe = a.sorted[sc->sidx[at]];
+          if (PBC) {
+            const int32_t wr = sc->swrap[at];
+            pe.x = add_rn(pe.x, (double)((wr & 3) - 1) * a.L[0]);
+            pe.y = add_rn(pe.y, (double)(((wr >> 2) & 3) - 1) * a.L[1]);
+            pe.z = add_rn(pe.z, (double)(((wr >> 4) & 3) - 1) * a.L[2]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < GC; k++) {
+          if (m_unc[k] == 0) continue;  // uniform
+          const double xe = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pi_l.x), k), __builtin_amdgcn_readlane(__double2loint(pi_l.x), k));
+          const double ye = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pi_l.y), k), __builtin_amdgcn_readlane(__double2loint(pi_l.y), k));
+          const double ze = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pi_l.z), k), __builtin_amdgcn_readlane(__double2loint(pi_l.z), k));
+          const double ex = sub_rn(pe.x, xe), ey = sub_rn(pe.y, ye), ez = sub_rn(pe.z, ze);
+          const double e2 = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
+          m_in[k] |= __builtin_amdgcn_ballot_w64(!(e2 > a.rc2)) & m_unc[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < GC; k++) {
+        const bool upper = NOSELF ? true : FULL ? pj.gid != gi[k] : pj.gid > gi[k];
+        mask[k] = NOSELF ? m_in[k] : m_in[k] & __builtin_amdgcn_ballot_w64(upper);
+        hit[k] = MODE == MODE_FILL ? ((mask[k] >> lane) & 1ull) != 0 : false;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < GC; k++) {
+        const T dx = sub_rn(pj.x, xi[k]), dy = sub_rn(pj.y, yi[k]), dz = sub_rn(pj.z, zi[k]);
+        const T r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+        // half list: j is kept by the particle with the smaller id; full list: everyone but i itself
+        const bool in_range = !(r2 > a.rc2), upper = NOSELF ? true : FULL ? pj.gid != gi[k] : pj.gid > gi[k];
+        hit[k] = in_range && upper;
+        mask[k] = NOSELF ? __builtin_amdgcn_ballot_w64(in_range)
+                         : __builtin_amdgcn_ballot_w64(in_range) & __builtin_amdgcn_ballot_w64(upper);
+      }
     }
 #pragma unroll
     for (int k = 0; k < GC; k++) {
@@ -807,7 +882,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const Pos
   // gid_j > gid_i, and their position 1e18 is never in range), so tiles need no per-lane tail handling.  Two register sets in ping-pong: the ds_read of the
   // next tile is in flight while the current one is tested, and no register copies are needed.
   const int32_t last = (ntiles - 1) * WAVE + lane;
-  Pos<T> pa = tile[lane], pb;
+  TileT pa = tile[lane], pb;
   int32_t t = 0;
   for (; t + 1 < ntiles; t += 2) {  // both tests unconditional, so neither load can be sunk next to its use
     pb = tile[(t + 1) * WAVE + lane];
@@ -911,11 +986,23 @@ template <typename T> __device__ __forceinline__ bool cell_setup_at(const SweepA
 }
 
 // The pair search of one cell: stage the stencil stream into `tile` (in batches of CAP), search it group by group.
-template <typename T, int MODE, int CAP = SweepCfg<T>::CAP, int NW = SWEEP_WAVES, bool FULL = false, bool PBC = false>
-__device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx& c, Pos<T>* tile, int tid, int lane,
+// SCREEN (fp64 only): `tile_raw` is screen_lds_bytes(CAP) bytes laid out as PosS[CAP] | sidx[CAP] | swrap[CAP] | float[NW].
+constexpr int screen_lds_bytes(int cap) { return cap * 21 + 32; }
+template <typename T, int MODE, int CAP = SweepCfg<T>::CAP, int NW = SWEEP_WAVES, bool FULL = false, bool PBC = false, bool SCREEN = false>
+__device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx& c, Pos<T>* tile_raw, int tid, int lane,
                                             int wave) {
   constexpr int G = SWEEP_G;
   static_assert(G == 5, "search_group dispatch covers group sizes 1..5");
+  typedef typename TileOf<T, SCREEN>::type TileT;
+  TileT* const tile = reinterpret_cast<TileT*>(tile_raw);
+  int32_t* const sidx = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(tile_raw) + (size_t)CAP * 16);
+  uint8_t* const swrap = reinterpret_cast<uint8_t*>(sidx + CAP);
+  float* const rmax_w = reinterpret_cast<float*>(reinterpret_cast<char*>(tile_raw) + ((size_t)CAP * 21 + 15) / 16 * 16);
+  // centre of the i-cell: origin of the relative coordinates of the screened search
+  T ox = 0, oy = 0, oz = 0;
+  if constexpr (SCREEN) {
+    ox = ((T)c.cx + (T)0.5) * a.ms[0], oy = ((T)c.cy + (T)0.5) * a.ms[1], oz = ((T)(c.cz + a.z_origin) + (T)0.5) * a.ms[2];
+  }
   const int32_t ibeg = c.ibeg, ni = c.ni, total_j = c.total_j;
   const int32_t nbatch = (total_j + CAP - 1) / CAP;
 
@@ -945,6 +1032,7 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
     // into flight before the first LDS write, 355 against 340 us at cfg 2 and 273 against 254 at cfg 3: in the loop below
     // the compiler waits for every load before it issues the next, 4-6 dependent round trips per wave and cell, and the
     // kernel is the faster for it.  profiles/r02_count_staging_ab.txt)
+    float rmax = 0.f;  // SCREEN: largest L1 norm of the relative coordinates this thread stages
     for (int32_t sg = wave; sg < NSEG; sg += NW) {
       const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
       if (len == 0) continue;
@@ -954,56 +1042,114 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       // segment; a template parameter because even a never-taken run-time branch here cost the open-box path 3-6 %.
       const int32_t wr = PBC ? __builtin_amdgcn_readlane(c.wrap, sg) : 0x15;  // (compile-time: the open-box kernels
                                                                               // carry none of this)
-      if (PBC && wr != 0x15) {
+      if constexpr (SCREEN) {
         const T sx = (T)((wr & 3) - 1) * a.L[0], sy = (T)(((wr >> 2) & 3) - 1) * a.L[1], sz = (T)(((wr >> 4) & 3) - 1) * a.L[2];
         for (int32_t k = lane; k < len; k += WAVE) {
           Pos<T> v0 = a.sorted[src + k];
-          v0.x = add_rn(v0.x, sx), v0.y = add_rn(v0.y, sy), v0.z = add_rn(v0.z, sz);
-          if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) tile[off + k] = v0;
+          if (PBC && wr != 0x15) v0.x = add_rn(v0.x, sx), v0.y = add_rn(v0.y, sy), v0.z = add_rn(v0.z, sz);
+          if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) {
+            PosS u;
+            u.x = (float)(v0.x - ox), u.y = (float)(v0.y - oy), u.z = (float)(v0.z - oz), u.gid = v0.gid;
+            tile[off + k] = u;
+            sidx[off + k] = src + k;
+            if (PBC) swrap[off + k] = (uint8_t)wr;
+            rmax = fmaxf(rmax, fabsf(u.x) + fabsf(u.y) + fabsf(u.z));
+          }
         }
-        continue;
-      }
-      for (int32_t k = lane; k < len; k += 2 * WAVE) {
-        const int32_t k1 = k + WAVE;
-        const bool p1 = k1 < len;
-        const Pos<T> v0 = a.sorted[src + k];
-        const Pos<T> v1 = a.sorted[src + (p1 ? k1 : k)];
-        if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) tile[off + k] = v0;
-        if (p1 && (nbatch == 1 || (uint32_t)(off + k1) < (uint32_t)CAP)) tile[off + k1] = v1;
+      } else {
+        if (PBC && wr != 0x15) {
+          const T sx = (T)((wr & 3) - 1) * a.L[0], sy = (T)(((wr >> 2) & 3) - 1) * a.L[1], sz = (T)(((wr >> 4) & 3) - 1) * a.L[2];
+          for (int32_t k = lane; k < len; k += WAVE) {
+            Pos<T> v0 = a.sorted[src + k];
+            v0.x = add_rn(v0.x, sx), v0.y = add_rn(v0.y, sy), v0.z = add_rn(v0.z, sz);
+            if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) tile[off + k] = v0;
+          }
+          continue;
+        }
+        for (int32_t k = lane; k < len; k += 2 * WAVE) {
+          const int32_t k1 = k + WAVE;
+          const bool p1 = k1 < len;
+          const Pos<T> v0 = a.sorted[src + k];
+          const Pos<T> v1 = a.sorted[src + (p1 ? k1 : k)];
+          if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) tile[off + k] = v0;
+          if (p1 && (nbatch == 1 || (uint32_t)(off + k1) < (uint32_t)CAP)) tile[off + k1] = v1;
+        }
       }
     }
     {  // sentinel padding up to the next tile boundary
       const int32_t pad = nj + tid;
       if (pad < ((nj + WAVE - 1) & ~(WAVE - 1))) {
-        Pos<T> sentinel;
         // far outside any box (r2 ~ 1e36 / 1e300, finite: never in range) AND an id that is never the upper one
-        sentinel.x = sizeof(T) == 4 ? (T)1.0e18f : (T)1.0e150, sentinel.y = 0, sentinel.z = 0, sentinel.gid = INT32_MIN;
-        if constexpr (sizeof(T) == 8) sentinel.row = 0;
-        tile[pad] = sentinel;
+        if constexpr (SCREEN) {
+          PosS sentinel;
+          sentinel.x = 1.0e18f, sentinel.y = 0.f, sentinel.z = 0.f, sentinel.gid = INT32_MIN;
+          tile[pad] = sentinel;
+          sidx[pad] = 0;
+          if (PBC) swrap[pad] = 0x15;
+        } else {
+          Pos<T> sentinel;
+          sentinel.x = sizeof(T) == 4 ? (T)1.0e18f : (T)1.0e150, sentinel.y = 0, sentinel.z = 0, sentinel.gid = INT32_MIN;
+          if constexpr (sizeof(T) == 8) sentinel.row = 0;
+          tile[pad] = sentinel;
+        }
       }
     }
+    if constexpr (SCREEN) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, d, WAVE));
+      if (lane == 0) rmax_w[wave] = rmax;
+    }
     __syncthreads();
+    float rj = 0.f;  // SCREEN: largest L1 norm of a staged particle's relative coordinates
+    if constexpr (SCREEN) {
+#pragma unroll
+      for (int w = 0; w < NW; w++) rj = fmaxf(rj, rmax_w[w]);
+    }
 
     // ---- search: this wave's groups against every tile of the batch
     const int32_t ntiles = (nj + WAVE - 1) / WAVE;
+    // A group's i-particles, rows and running counts are loaded one group ahead (dense cells: a wave has a dozen groups
+    // per batch, and each group's own loads -- position -> row -> progress, dependent -- cost as much as its search).
+    // Unconditional loads of valid slots (a load under a branch is waited for at the join).
+    Pos<T> pre_p;
+    int32_t pre_row = 0, pre_prog = 0;
+    int64_t pre_base = 0;
+    auto fetch_group = [&](int32_t g) {
+      const int32_t idx = ibeg + min(g * gsize + lane, ni - 1);
+      pre_p = a.sorted[idx];
+      pre_row = a.sorted_row[idx];
+      if (MODE == MODE_FILL)
+        pre_base = a.wide ? static_cast<const int64_t*>(a.key_pointer)[pre_row] : (int64_t)static_cast<const int32_t*>(a.key_pointer)[pre_row];
+      pre_prog = batch ? a.progress[pre_row] : 0;  // entries already produced by earlier batches
+    };
+    if (wave < ngroups) fetch_group(wave);
     for (int32_t g = wave; g < ngroups; g += NW) {
       const int32_t i0 = g * gsize;
       const int32_t gcount = min(gsize, ni - i0);  // wave-uniform; may be <= 0 for the last groups
       if (gcount <= 0) break;
       // lane k < gcount holds i-particle k of the group
-      Pos<T> pi_l;
-      pi_l.x = 0, pi_l.y = 0, pi_l.z = 0, pi_l.gid = 0;
-      int32_t row_l = 0;
-      int64_t base_l = 0;
-      if (lane < gcount) {
-        pi_l = a.sorted[ibeg + i0 + lane];
-        row_l = a.sorted_row[ibeg + i0 + lane];
-        if (MODE == MODE_FILL)
-          base_l = a.wide ? static_cast<const int64_t*>(a.key_pointer)[row_l] : (int64_t)static_cast<const int32_t*>(a.key_pointer)[row_l];
-        if (batch) base_l += a.progress[row_l];  // entries already produced by earlier batches
-      }
+      Pos<T> pi_l = pre_p;
+      const int32_t row_l = pre_row, before = pre_prog;
+      int64_t base_l = pre_base + before;
+      if (lane >= gcount) pi_l.x = 0, pi_l.y = 0, pi_l.z = 0, pi_l.gid = 0;
+      if (g + NW < ngroups && (g + NW) * gsize < ni) fetch_group(g + NW);
       const int32_t slot0 = ibeg + i0;
-      // hit masks are kept only for single-batch cells (k_fill_masks re-searches the rest)
+      // SCREEN: the i-particles relative to the cell centre, as floats, and the band of this group against this batch
+      float uxi = 0.f, uyi = 0.f, uzi = 0.f;
+      ScreenCtx sc;
+      sc.lo = sc.hi = 0.f, sc.sidx = sidx, sc.swrap = swrap;
+      if constexpr (SCREEN) {
+        float ri = 0.f;
+        if (lane < gcount) {
+          uxi = (float)(pi_l.x - ox), uyi = (float)(pi_l.y - oy), uzi = (float)(pi_l.z - oz);
+          ri = fabsf(uxi) + fabsf(uyi) + fabsf(uzi);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) ri = fmaxf(ri, __shfl_xor(ri, d, WAVE));
+        const float rc2f = (float)a.rc2;
+        const float band = 9.5367432e-7f * (ri + rj) * (ri + rj) + 2.3841858e-7f * rc2f;  // 16 2^-24 S + 4 2^-24 rc2
+        sc.lo = rc2f - band, sc.hi = rc2f + band;
+      }
       // hit masks are kept for cells whose stencil fits the mask rows the build provides per slot: one LDS batch in the
       // usual regime, up to FD_NB in a dense build (k_fill_dense); the expansion kernels re-search the rest
       const bool keep = nbatch <= a.mask_nb && CAP == SweepCfg<T>::CAP;
@@ -1011,26 +1157,25 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       if constexpr (CAN_NOSELF) {
         if (nbatch == 1) {  // (uniform) the row's own particle is in this, the only, batch
           switch (gcount) {
-            case 1: mine = search_group<T, MODE, 1, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
-            case 2: mine = search_group<T, MODE, 2, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
-            case 3: mine = search_group<T, MODE, 3, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
-            case 4: mine = search_group<T, MODE, 4, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
-            default: mine = search_group<T, MODE, 5, FULL, true>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0); break;
+            case 1: mine = search_group<T, MODE, 1, FULL, true, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0, 0, &sc, uxi, uyi, uzi); break;
+            case 2: mine = search_group<T, MODE, 2, FULL, true, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0, 0, &sc, uxi, uyi, uzi); break;
+            case 3: mine = search_group<T, MODE, 3, FULL, true, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0, 0, &sc, uxi, uyi, uzi); break;
+            case 4: mine = search_group<T, MODE, 4, FULL, true, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0, 0, &sc, uxi, uyi, uzi); break;
+            default: mine = search_group<T, MODE, 5, FULL, true, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, own + i0, 0, &sc, uxi, uyi, uzi); break;
           }
           if (lane < gcount) a.count[row_l] = mine;
           continue;
         }
       }
       switch (gcount) {
-        case 1: mine = search_group<T, MODE, 1, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
-        case 2: mine = search_group<T, MODE, 2, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
-        case 3: mine = search_group<T, MODE, 3, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
-        case 4: mine = search_group<T, MODE, 4, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
-        default: mine = search_group<T, MODE, 5, FULL>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch); break;
+        case 1: mine = search_group<T, MODE, 1, FULL, false, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch, &sc, uxi, uyi, uzi); break;
+        case 2: mine = search_group<T, MODE, 2, FULL, false, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch, &sc, uxi, uyi, uzi); break;
+        case 3: mine = search_group<T, MODE, 3, FULL, false, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch, &sc, uxi, uyi, uzi); break;
+        case 4: mine = search_group<T, MODE, 4, FULL, false, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch, &sc, uxi, uyi, uzi); break;
+        default: mine = search_group<T, MODE, 5, FULL, false, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch, &sc, uxi, uyi, uzi); break;
       }
       if (lane < gcount) {
         if (nbatch > 1) {
-          const int32_t before = batch ? a.progress[row_l] : 0;
           mine += before;
           a.progress[row_l] = mine;
         }
@@ -1048,7 +1193,9 @@ template <typename T, int MODE> constexpr int sweep_cap() { return SweepCfg<T>::
 template <typename T, int MODE, bool FULL = false, bool PBC = false>
 __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   constexpr int CAP = sweep_cap<T, MODE>();
-  __shared__ Pos<T> tile[CAP];
+  constexpr bool SCREEN = sizeof(T) == 8;  // fp64 sweeps: fp32 screening + exact test inside the band (search_group)
+  __shared__ __attribute__((aligned(32))) char tile_bytes[SCREEN ? screen_lds_bytes(CAP) : CAP * (int)sizeof(Pos<T>)];
+  Pos<T>* const tile = reinterpret_cast<Pos<T>*>(tile_bytes);
   if (MODE == MODE_FILL) {
     if (a.total[0] > a.capacity) {  // uniform: every workgroup leaves, nothing is written out of bounds
       if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
@@ -1072,7 +1219,7 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
     c.ibeg += lo, c.ni = hi - lo;
     if (c.ni <= 0) return;
   }
-  cell_search<T, MODE, CAP, SWEEP_WAVES, FULL, PBC>(a, c, tile, tid, lane, wave);
+  cell_search<T, MODE, CAP, SWEEP_WAVES, FULL, PBC, SCREEN>(a, c, tile, tid, lane, wave);
 }
 
 template <typename T, int MODE, bool FULL = false, bool PBC = false>
