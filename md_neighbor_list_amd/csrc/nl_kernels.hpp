@@ -1122,17 +1122,19 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
         pre_base = a.wide ? static_cast<const int64_t*>(a.key_pointer)[pre_row] : (int64_t)static_cast<const int32_t*>(a.key_pointer)[pre_row];
       pre_prog = batch ? a.progress[pre_row] : 0;  // entries already produced by earlier batches
     };
-    if (wave < ngroups) fetch_group(wave);
+    const bool ahead = !(a.dbg & 1024);  // diagnostics: 1024 = every group fetches its own data when it starts
+    if (wave < ngroups && ahead) fetch_group(wave);
     for (int32_t g = wave; g < ngroups; g += NW) {
       const int32_t i0 = g * gsize;
       const int32_t gcount = min(gsize, ni - i0);  // wave-uniform; may be <= 0 for the last groups
       if (gcount <= 0) break;
       // lane k < gcount holds i-particle k of the group
+      if (!ahead) fetch_group(g);
       Pos<T> pi_l = pre_p;
       const int32_t row_l = pre_row, before = pre_prog;
       int64_t base_l = pre_base + before;
       if (lane >= gcount) pi_l.x = 0, pi_l.y = 0, pi_l.z = 0, pi_l.gid = 0;
-      if (g + NW < ngroups && (g + NW) * gsize < ni) fetch_group(g + NW);
+      if (ahead && g + NW < ngroups && (g + NW) * gsize < ni) fetch_group(g + NW);
       const int32_t slot0 = ibeg + i0;
       // SCREEN: the i-particles relative to the cell centre, as floats, and the band of this group against this batch
       float uxi = 0.f, uyi = 0.f, uzi = 0.f;
