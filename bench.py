@@ -175,7 +175,8 @@ def _stage_table(stages, info, n, p, vec_bytes, pos_bytes, full=False):
     """Every stage of the build with the bytes THAT stage moves by design (reads + writes of its own arrays; cache
     re-reads of the stencil are not counted) and its HIP-event time.  n = particles on this device, p = list entries."""
     rows = []
-    masks = 192 * n if info["masks"] else 0
+    nb = max(1, info.get("mask_rows", 1))
+    masks = 192 * n * nb if info["masks"] else 0
 
     def add(name, key, nbytes, what):
         ms = stages.get(key, 0.0)
@@ -189,10 +190,10 @@ def _stage_table(stages, info, n, p, vec_bytes, pos_bytes, full=False):
     add("binning 2+3 (k_bin_scatter, k_bin_cells)", "reorder", vec_bytes * n + 2 * (pos_bytes + 4) * n + (pos_bytes + 8) * n,
         "positions read; row-grouped copy written and read; sorted positions + row + id written")
     add("pair search COUNT" + (" keeping hit masks" if info["masks"] else ""), "count", (pos_bytes + 4) * n + 4 * n + masks,
-        "sorted positions + rows read once, counts" + (" and 192 B of hit masks per particle" if info["masks"] else "") + " written")
+        "sorted positions + rows read once, counts" + (f" and {192 * nb} B of hit masks per particle" if info["masks"] else "") + " written")
     add("row scan (+ row offsets in cell order)", "row_scan", 4 * n + 4 * n + 4 * n, "counts read twice, key_pointer written")
     if info["masks"]:
-        add("expansion (k_row_base, k_fill_masks)", "fill", masks + 12 * n + 4 * n + 4 * p,
+        add("expansion (k_row_base, " + ("k_fill_dense" if nb > 1 else "k_fill_masks") + ")", "fill", masks + 12 * n + 4 * n + 4 * p,
             "hit masks, ids, row offsets read; the list written")
     else:
         add("pair search FILL", "fill", (pos_bytes + 4) * n + 4 * n + 4 * p, "sorted positions + offsets read; the list written")

@@ -279,7 +279,8 @@ int nl_debug_read(nl_handle_t h, uint64_t* out, int32_t n, int reset);
 int nl_debug_occupancy(int32_t out[8]); /* LDS per CU/block (KiB), occupancy API answers, LDS bytes, registers */
 /* How the last build was organised: info[0] = 1 when the COUNT sweep kept hit masks and the list was expanded from
  * them (0: two distance sweeps), info[1] = configured sweep variant, info[2] = LDS batch capacity (particles),
- * info[3] = compute units of the device, info[4] = width of the list offsets the build used (32 / 64), info[5..7] = 0. */
+ * info[3] = compute units of the device, info[4] = width of the list offsets the build used (32 / 64), info[5] = mask rows per particle (1; up to 7 in a
+ * dense build: one per LDS batch of the stencil stream), info[6] = 1 for the half-shell search, info[7] = 0. */
 int nl_get_build_info(nl_handle_t h, int32_t info[8]);
 int nl_last_error(nl_handle_t h);     /* status of the last failed call on this handle */
 int nl_last_hip_error(nl_handle_t h); /* raw hipError_t behind the last NL_ERR_HIP */

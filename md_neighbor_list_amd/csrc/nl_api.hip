@@ -1187,6 +1187,8 @@ int nl_get_build_info(nl_handle_t h, int32_t info[8]) {
   if (!h || !info) return NL_ERR_ARG;
   for (int k = 4; k < 8; k++) info[k] = 0;
   info[4] = h->b_wide ? 64 : 32;
+  info[5] = h->b_mask_nb;
+  info[6] = h->b_half ? 1 : 0;
   info[0] = h->b_use_masks ? 1 : 0;
   info[1] = h->sweep_variant;
   info[2] = h->dtype == NL_F32 ? SweepCfg<float>::CAP : SweepCfg<double>::CAP;

@@ -316,12 +316,12 @@ class NeighListGPU:
 
 
     def build_info(self):
-        """{'masks': bool, 'variant': int, 'lds_batch': int, 'cus': int, 'offset_bits': 32 | 64} of the last build
-        (masks: the list was expanded from hit masks)."""
+        """{'masks': bool, 'variant': int, 'lds_batch': int, 'cus': int, 'offset_bits': 32 | 64, 'mask_rows': int,
+        'half_shell': bool} of the last build (masks: the list was expanded from hit masks; mask_rows > 1: dense build)."""
         info = (C.c_int32 * 8)()
         check(self._lib.nl_get_build_info(self._h, C.byref(info)), "nl_get_build_info")
         return {"masks": bool(info[0]), "variant": int(info[1]), "lds_batch": int(info[2]), "cus": int(info[3]),
-                "offset_bits": int(info[4])}
+                "offset_bits": int(info[4]), "mask_rows": int(info[5]), "half_shell": bool(info[6])}
 
     def profile_last_build(self, reps=10):
         """Same for the last build (also a slab build); its position/id tensors are kept alive by this object."""

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Soak: many seeded random problems (all sweep variants, both binning paths, both dtypes, half and full lists)
-against the oracle.  usage: tools/soak_parity.py [cases] [seed]"""
+"""Soak: many seeded random problems (all sweep variants, both binning paths, both dtypes, both offset widths, half and
+full lists, open box and minimum image, uniform and clustered particles -- dense cells among sparse ones exercise the
+re-search paths, the dense-mask pipeline and the half-shell variant's 27-cell fall-back) against the oracle.
+usage: tools/soak_parity.py [cases] [seed]"""
 import os
 import sys
 
@@ -17,7 +19,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 bad = 0
 for case in range(cases):
     dtype = np.float32 if rng.random() < 0.6 else np.float64
-    os.environ["NL_SWEEP_VARIANT"] = os.environ.get("SOAK_VARIANT") or str(rng.integers(1, 6))
+    os.environ["NL_SWEEP_VARIANT"] = os.environ.get("SOAK_VARIANT") or str(rng.choice([1, 3, 3, 5, 6]))
+    os.environ["NL_OFFSET_WIDTH"] = str(rng.choice([0, 0, 64]))
     os.environ["NL_BINNING"] = str(rng.integers(0, 2))
     rc = float(rng.uniform(0.5, 5.0))
     mesh = rng.integers(3, 14, size=3)
@@ -26,6 +29,11 @@ for case in range(cases):
     n = int(min(120000, max(1, ncell * rng.uniform(*((10.0, 45.0) if os.environ.get("SOAK_VARIANT") else (0.05, 60.0))))))
     q = np.zeros((n, 4), dtype=dtype)
     q[:, :3] = rng.uniform(0.0, 1.0, size=(n, 3)) * np.array(box)
+    if rng.random() < 0.25:  # a cluster: a third of the particles in a few cells
+        k = n // 3
+        centre = rng.uniform(0.2, 0.8, size=3) * np.array(box)
+        q[:k, :3] = centre + rng.uniform(-1.0, 1.0, size=(k, 3)) * rc * rng.uniform(0.6, 2.0)
+        q[:k, :3] = np.clip(q[:k, :3], 0.0, None)
     q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=dtype), dtype(0)))
     full = rng.random() < 0.3
     pbc = rng.random() < 0.3
@@ -52,12 +60,13 @@ for case in range(cases):
                 hk = np.concatenate([[0], np.cumsum(np.bincount(rows[half], minlength=n))])
                 ok = np.array_equal(canonical_csr(hk, lst[half]), ref.sorted_list)
         else:
-            kp, sl = nl.key_pointer().cpu().numpy(), nl.sorted_list().cpu().numpy()
+            kp, sl = nl.key_pointer64().cpu().numpy(), nl.sorted_list().cpu().numpy()
             ok = int(kp[-1]) == ref.npairs and np.array_equal(canonical_csr(kp, sl), ref.sorted_list)
+            ok = ok and nl.list_checksum() == (ref.hash(), ref.npairs)
         if not ok:
             bad += 1
             print(f"MISMATCH case {case} rep {rep}: n={n} box={box} rc={rc} dtype={dtype.__name__} full={full} "
-                  f"pbc={pbc} variant={os.environ['NL_SWEEP_VARIANT']} binning={os.environ['NL_BINNING']} info={nl.build_info()}", flush=True)
+                  f"pbc={pbc} variant={os.environ['NL_SWEEP_VARIANT']} width={os.environ['NL_OFFSET_WIDTH']} binning={os.environ['NL_BINNING']} info={nl.build_info()}", flush=True)
     if case % 50 == 49:
         print(f"{case + 1} cases, {bad} mismatches", flush=True)
 print(f"soak done: {cases} cases, {bad} mismatches")

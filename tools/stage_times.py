@@ -79,9 +79,3 @@ for name in sys.argv[1:] or ["cfg2", "cfg3"]:
             key = xcc * 1000 + se * 16 + cu
             uniq, cnt = np.unique(key[~late], return_counts=True)
             print(f"   distinct (xcc,se,cu) among the early ones: {len(uniq)}; workgroups per CU histogram: {np.bincount(cnt)}")
-    if flags & 4 and nl.build_info().get("mfma"):
-        rec = buf[64:64 + 2048 * 8].reshape(2048, 8)[:, :6].astype(np.float64)
-        rec = rec[rec.sum(axis=1) > 0]
-        names = ["cell table", "staging", "barrier", "search+stores", "barrier", "counts"]
-        print("   k_sweep_mfma_f32 thread-0 cycles per cell: " + "  ".join(f"{nm} {rec[:, i].mean():.0f}" for i, nm in enumerate(names))
-              + f"  (total {rec.sum(axis=1).mean():.0f}, {len(rec)} records)")
