@@ -188,8 +188,15 @@ def exchange_ghosts(st: SlabState, defer: bool = False):
     return _p2p(sends + recvs, _staging(), defer)
 
 
-def build(nl, st: SlabState, sync=True, overlap=True) -> None:
-    """One domain-decomposed build on this rank: halo exchange, then the slab build on owned + ghost particles."""
+def build(nl, st: SlabState, sync=True, overlap=None) -> None:
+    """One domain-decomposed build on this rank: halo exchange, then the slab build on owned + ghost particles.
+    overlap: run the binning of the owned layers under the transfer (nl_make_list_slab_begin / _finish).  Default: on
+    over gloo, where every test runs it; OFF over nccl, whose deferred completion has never run on hardware
+    -- NL_SLAB_OVERLAP=1 turns it on there."""
+    import os
+
+    if overlap is None:
+        overlap = dist.get_backend() != "nccl" or os.environ.get("NL_SLAB_OVERLAP") == "1" if st.world > 1 else False
     gid = nl.GID_IN_W if st.q_all.shape[1] == 4 else st.gid_all
     if st.world == 1:
         nl.MakeNeighListSlab(st.q_all, gid, st.n_rows, 0, nl.mesh_size[2], sync=sync)
