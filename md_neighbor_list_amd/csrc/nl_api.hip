@@ -301,9 +301,9 @@ template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_half(n
                        h->n_rows, h->n, static_cast<OFF*>(h->base_sorted));
   SweepArgs<T> ah = a;
   ah.cells_per_block = h->half_cpb, ah.ncells_grid = ncells_i;
-  hipLaunchKernelGGL((k_fill_half<T, FULL, PBC, OFF>), dim3((ncells_i + h->half_cpb - 1) / h->half_cpb), dim3(HF_WAVES * WAVE), 0, s, ah,
+  hipLaunchKernelGGL((k_fill_half<T, FULL, false, OFF>), dim3((ncells_i + h->half_cpb - 1) / h->half_cpb), dim3(HF_WAVES * WAVE), 0, s, ah,
                      static_cast<const OFF*>(h->base_sorted));
-  hipLaunchKernelGGL((k_full27<T, MODE_FILL, FULL, PBC>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
+  hipLaunchKernelGGL((k_full27<T, MODE_FILL, FULL, false>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
 }
 
 template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h, int mode, hipStream_t s) {
@@ -315,9 +315,9 @@ template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h,
     const int32_t ncells_h = h->m[0] * h->m[1] * (h->b_slab ? h->b_mzl - 1 : h->b_mzl);
     SweepArgs<T> ah = a;
     ah.cells_per_block = h->half_cpb, ah.ncells_grid = ncells_h;
-    hipLaunchKernelGGL((k_sweep_half<T, FULL, PBC>), dim3((ncells_h + h->half_cpb - 1) / h->half_cpb), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
+    hipLaunchKernelGGL((k_sweep_half<T, FULL, false>), dim3((ncells_h + h->half_cpb - 1) / h->half_cpb), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
     ah.ncells_grid = ncells_i;  // cells with an irregular stencil: counted by the 27-cell search
-    hipLaunchKernelGGL((k_full27<T, MODE_COUNT, FULL, PBC>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
+    hipLaunchKernelGGL((k_full27<T, MODE_COUNT, FULL, false>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
     if (h->n > 0)
       hipLaunchKernelGGL(k_half_counts, dim3((h->n + 255) / 256), dim3(256), 0, s, h->fcnt, h->rcnt, h->rstride, h->sorted_row,
                          h->n_rows, h->n, h->count);
@@ -370,6 +370,21 @@ template <typename T> void launch_sweep(nl_handle_t h, int mode, hipStream_t s) 
 // expansion).  BEGIN + FINISH = ALL for the caller; between the two the halo exchange may still be writing the ghosts.
 enum { PART_ALL = 0, PART_BEGIN = 1, PART_FINISH = 2 };
 
+// Mask rows for `nb` LDS batches per particle: allocated on first need (a half-shell handle that meets a minimum-image
+// or dense build; a first dense build).
+bool mask_rows_ready(nl_handle_t h, int64_t nb) {
+  const size_t need = (size_t)MASK_ROW_BYTES * (size_t)nb * ((size_t)h->n_max + 16);
+  if (need > h->dense_masks_limit) return false;
+  if (need > h->masks_bytes || !h->masks) {
+    if (dev_alloc(h, &h->masks, need) != NL_OK) {
+      h->masks_bytes = 0;
+      return false;
+    }
+    h->masks_bytes = need;
+  }
+  return true;
+}
+
 // What the handle remembers about the build being enqueued (also set when a captured graph of it is replayed): how the
 // later stages, the getters and a refill after growth have to read the buffers.
 template <typename T>
@@ -385,20 +400,18 @@ void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int
   // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
   const double mean_stream = ncl > 0 ? 27.0 * n / (double)ncl : 0.0;
   const bool sparse_enough = mean_stream <= 0.85 * SweepCfg<T>::CAP;  // mean stencil <= 1088: <= 40.3 per cell
-  h->b_half = h->b_variant >= 5 && h->fmask && sparse_enough;
-  h->b_use_masks = h->b_variant >= 3 && h->b_variant < 5 && h->masks && sparse_enough;
+  // (open box only: in minimum-image mode a pair is decided in the frame of the row that stores it -- (q_j + L) - q_i
+  // and (q_i - L) - q_j round differently -- and the half-shell search tests a pair once, in the frame of the lower
+  // cell's particle, whichever row stores it: a seeded soak found the one-ulp case.  Such builds take variant 3.)
+  h->b_half = h->b_variant >= 5 && h->fmask && sparse_enough && !h->pbc;
+  if (h->b_variant >= 5 && !h->b_half) h->b_variant = 3;
+  h->b_use_masks = h->b_variant >= 3 && h->b_variant < 5 && sparse_enough && mask_rows_ready(h, 1);
   h->b_mask_nb = 1;
   if (h->b_variant >= 3 && !sparse_enough && !h->dense_masks_off) {
     // Dense cells: hit masks for up to FD_NB LDS batches per slot instead of a second distance sweep, when the streams
     // (mean + 5 sigma of a Poisson count) fit that many batches and the mask rows fit the memory set aside for them
     const int64_t nb = (int64_t)((mean_stream + 5.0 * std::sqrt(mean_stream) + 64.0) / SweepCfg<T>::CAP) + 1;
-    const size_t need = (size_t)MASK_ROW_BYTES * (size_t)nb * ((size_t)h->n_max + 16);
-    if (nb <= FD_NB && need <= h->dense_masks_limit) {
-      if (need > h->masks_bytes) {  // (synchronous allocation: first dense build of the handle only)
-        if (h->pending_alloc_ok && dev_alloc(h, &h->masks, need) == NL_OK) h->masks_bytes = need;
-      }
-      if (need <= h->masks_bytes && h->masks) h->b_use_masks = true, h->b_mask_nb = (int32_t)nb;
-    }
+    if (nb <= FD_NB && mask_rows_ready(h, nb)) h->b_use_masks = true, h->b_mask_nb = (int32_t)nb;  // (allocates once)
   }
   // 64-bit list offsets as soon as the list this handle can hold exceeds what an int32 key_pointer can address
   // (the reference's own limit, neighlist_cpu.hpp:15,29); nl_set_offset_width overrides.
