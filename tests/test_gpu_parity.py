@@ -121,6 +121,34 @@ def test_full_transposed_list_matches_gpu_harness_check():
     assert nhalf == ref.npairs and h == ref.hash()
 
 
+@pytest.mark.parametrize("n,box,rc", [(70001, (42.0, 40.0, 38.0), 3.3),    # rows ~150: the flat LDS conversion
+                                        (30000, (20.0, 21.0, 19.0), 3.3)])   # rows ~560: blocks left to the tiled kernel
+def test_transposed_list_from_the_full_csr(n, box, rc):
+    """nl_get_full_transposed after a NL_LIST_FULL build -- the reference GPU class's layout list[k*N + i]
+    (neighlist_gpu.hpp:468-482) -- through both conversion kernels: every column holds exactly the row of the full CSR,
+    -1 beyond it, and its j > i part hashes to the oracle's half list."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    q, box = inputs.uniform_box(n, dtype=np.float32, seed=52, box=box)
+    ref = _po().build(q, rc, box)
+    nl = NeighListGPU(rc, *box, dtype=torch.float32, full_list=True)
+    nl.Initialize(n)
+    nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+    kp, lst, cnt = (t.cpu().numpy() for t in nl.full_csr())
+    tl = nl.neigh_list().cpu().numpy()
+    tc = nl.number_of_partners().cpu().numpy()
+    assert np.array_equal(tc, cnt) and tl.shape[1] == n and tl.shape[0] >= cnt.max()
+    k = np.arange(tl.shape[0])[:, None]
+    assert np.all(tl[k >= cnt[None, :]] == -1)
+    rows = np.repeat(np.arange(n), cnt)
+    ks = np.arange(len(lst)) - np.repeat(kp[:-1].astype(np.int64), cnt)
+    assert np.array_equal(tl[ks, rows], lst)  # column i, entries 0..cnt[i]) = row i of the CSR, in its order
+    h, nhalf = _po().hash_transposed(cnt, tl, n)
+    assert nhalf == ref.npairs and h == ref.hash()
+
+
 def test_errors_are_reported_not_crashes():
     import torch
 
