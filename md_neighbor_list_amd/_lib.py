@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnl_hip.so")
+# NL_HIP_LIB: another build of the same library (kernel A/B runs, tools/ab_libs.sh); never a different implementation
+LIB_PATH = os.environ.get("NL_HIP_LIB") or os.path.join(_HERE, "lib", "libnl_hip.so")
 
 NL_F32, NL_F64 = 0, 1
 NL_OK = 0

@@ -83,7 +83,6 @@ struct nl_handle_s {
   int isplit_env = 0;              // NL_ISPLIT: 0 = by density
   bool dense_masks_off = false;    // NL_DENSE_MASKS=0: dense builds use two distance sweeps (the round-1 path)
   size_t dense_masks_limit = (size_t)64 << 30;  // most memory the mask rows of a dense build may take
-  bool pending_alloc_ok = true;
   int half_cpb = 4;                // cells a workgroup of k_sweep_half walks (NL_HALF_CPB)
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps;
                                    // 3 (default): COUNT keeping hit masks + mask expansion

@@ -202,6 +202,17 @@ __device__ __forceinline__ int32_t scan32_dpp(int32_t v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
   return v;
 }
+// Sum over the 64 lanes (6 DPP adds + one v_readlane): wave-uniform result.
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t x) {
+  int32_t v = (int32_t)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
 
 __device__ __forceinline__ int64_t wave_incl_scan64(int64_t v, int lane) {
 #pragma unroll
@@ -745,6 +756,56 @@ struct ScreenCtx {
 template <typename T, bool SCREEN> struct TileOf { typedef Pos<T> type; };
 template <typename T> struct TileOf<T, true> { typedef PosS type; };
 
+#ifndef NL_VBITS
+#define NL_VBITS 1
+#endif
+#ifndef NL_VBITS_SPLIT
+#define NL_VBITS_SPLIT 1
+#endif
+#ifndef NL_PKMUL
+#define NL_PKMUL 0
+#endif
+#ifndef NL_COUNT_WPE
+#define NL_COUNT_WPE 0
+#endif
+#ifndef NL_STAMP  // timing experiments only: per-phase wave cycles of the COUNT_MASKS sweep into dbg_buf[16..] (tools/count_phases.py)
+#define NL_STAMP 0
+#endif
+#ifndef NL_DIAG  // timing experiments only (wrong lists): 1 = no tile tests, 2 = no mask stores, 4 = no staging loads
+#define NL_DIAG 0
+#endif
+// r2 of one staged fp32 particle against the GC i-particles: the reference's expression, every operation rounded on
+// its own.  NL_PKMUL: the squares of two tests go through one v_pk_mul_f32 (each half is an IEEE multiply: same bits);
+// the subtractions and sums stay single instructions, which issue faster than their packed forms on gfx950.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int GC>
+__device__ __forceinline__ void r2_group_f32(float xj, float yj, float zj, const float* xi, const float* yi, const float* zi, float* r2) {
+#if NL_PKMUL
+#pragma unroll
+  for (int k = 0; k + 1 < GC; k += 2) {
+    const f32x2 dx = {sub_rn(xj, xi[k]), sub_rn(xj, xi[k + 1])};
+    const f32x2 dy = {sub_rn(yj, yi[k]), sub_rn(yj, yi[k + 1])};
+    const f32x2 dz = {sub_rn(zj, zi[k]), sub_rn(zj, zi[k + 1])};
+    const f32x2 sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    r2[k] = add_rn(add_rn(sx.x, sy.x), sz.x);
+    r2[k + 1] = add_rn(add_rn(sx.y, sy.y), sz.y);
+  }
+  if (GC & 1) {
+    constexpr int k = GC - 1;
+    const f32x2 d = {sub_rn(xj, xi[k]), sub_rn(yj, yi[k])};
+    const float dz = sub_rn(zj, zi[k]);
+    const f32x2 sq = d * d;
+    r2[k] = add_rn(add_rn(sq.x, sq.y), mul_rn(dz, dz));
+  }
+#else
+#pragma unroll
+  for (int k = 0; k < GC; k++) {
+    const float dx = sub_rn(xj, xi[k]), dy = sub_rn(yj, yi[k]), dz = sub_rn(zj, zi[k]);
+    r2[k] = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+  }
+#endif
+}
+
 // One group of GC (compile-time, 1..5) i-particles against the nj staged j-particles.
 // pi_l / base_l: lane k < GC holds i-particle k and the list offset of its row.  Returns, in lane k, the number
 // of accepted partners of i-particle k.  All per-i state is wave-uniform (SGPRs): position, id, running count.
@@ -770,6 +831,15 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   uint32_t cur[GC];  // hits so far
   int32_t* rowp[GC];  // FILL: where the row's next entry goes (wave-uniform 64-bit pointer: the list may exceed 2^31 entries)
   uint32_t bits[GC];  // COUNT_MASKS: bit t of lane l = staged particle t*64 + l accepted
+  // VBITS (fp32 COUNT_MASKS, half list or NOSELF): the accept decision never leaves the vector unit.  Sign bit of
+  // rc2 - r2 clear <=> !(r2 > rc2) (coordinates are finite: the binning rejects the rest); sign bit of
+  // gid_j - (gid_i + 1) clear <=> gid_j > gid_i (ids are non-negative; the sentinels' INT32_MIN wraps to "greater" but
+  // they are never in range).  OR the two words and v_alignbit the sign into the lane's word: four 2-operand VALU
+  // instructions per test where two v_cmp (SGPR-pair results), an s_and, an add-with-carry, an s_bcnt1 and an s_add
+  // were -- and no VALU -> SALU -> VALU dependency inside a tile.  The word collects NOT-accepted bits; inverted, and
+  // the row counted from it (popcount + one DPP sum per i-particle), after the last tile.
+  constexpr bool VBITS = NL_VBITS && MODE == MODE_COUNT_MASKS && !SCREEN && sizeof(T) == 4 && (!FULL || NOSELF);
+  uint32_t gi1[GC];
 #pragma unroll
   for (int k = 0; k < GC; k++) bits[k] = 0;
 #pragma unroll
@@ -789,6 +859,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
     }
     gi[k] = __builtin_amdgcn_readlane(pi_l.gid, k);
     cur[k] = 0u;
+    gi1[k] = (uint32_t)gi[k] + 1u;
     if (MODE == MODE_FILL) {
       const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)base_l, k);
       const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)((uint64_t)base_l >> 32), k);
@@ -800,6 +871,21 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   // tests comes first (masks land in SGPR pairs), the scalar bookkeeping afterwards: a scalar instruction that
   // consumes a v_cmp result stalls the wave until the compare has left the VALU.
   auto test_tile = [&](const TileT& pj, int32_t tix) {
+    if constexpr (VBITS) {
+      // The tests go in two parts with a scheduling barrier between them: left alone the compiler hoists the
+      // subtractions of all GC tests to the top of the tile, 4 live registers per test, and the kernel loses a wave per SIMD.
+      constexpr int HALF = NL_VBITS_SPLIT ? (GC + 1) / 2 : GC;
+#pragma unroll
+      for (int k = 0; k < GC; k++) {
+        if (k == HALF) __builtin_amdgcn_sched_barrier(0);
+        const float dx = sub_rn(pj.x, xi[k]), dy = sub_rn(pj.y, yi[k]), dz = sub_rn(pj.z, zi[k]);
+        const float r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+        uint32_t w = __builtin_bit_cast(uint32_t, sub_rn((float)a.rc2, r2));
+        if (!NOSELF) w |= (uint32_t)pj.gid - gi1[k];
+        bits[k] = __builtin_amdgcn_alignbit(bits[k], w, 31);  // 2 bits + (w >> 31)
+      }
+      return;
+    }
     uint64_t mask[GC];
     bool hit[GC];  // per-lane predicate: lives in an SGPR pair as a lane mask, costs no VALU
     if constexpr (SCREEN) {
@@ -845,10 +931,19 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
         hit[k] = MODE == MODE_FILL ? ((mask[k] >> lane) & 1ull) != 0 : false;
       }
     } else {
+      T r2g[GC];
+      if constexpr (sizeof(T) == 4) {
+        r2_group_f32<GC>(pj.x, pj.y, pj.z, xi, yi, zi, r2g);
+      } else {
+#pragma unroll
+        for (int k = 0; k < GC; k++) {
+          const T dx = sub_rn(pj.x, xi[k]), dy = sub_rn(pj.y, yi[k]), dz = sub_rn(pj.z, zi[k]);
+          r2g[k] = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+        }
+      }
 #pragma unroll
       for (int k = 0; k < GC; k++) {
-        const T dx = sub_rn(pj.x, xi[k]), dy = sub_rn(pj.y, yi[k]), dz = sub_rn(pj.z, zi[k]);
-        const T r2 = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
+        const T r2 = r2g[k];
         // half list: j is kept by the particle with the smaller id; full list: everyone but i itself
         const bool in_range = !(r2 > a.rc2), upper = NOSELF ? true : FULL ? pj.gid != gi[k] : pj.gid > gi[k];
         hit[k] = in_range && upper;
@@ -883,7 +978,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   // next tile is in flight while the current one is tested, and no register copies are needed.
   const int32_t last = (ntiles - 1) * WAVE + lane;
   TileT pa = tile[lane], pb;
-  int32_t t = 0;
+  int32_t t = (NL_DIAG & 1) ? ntiles : 0;
   for (; t + 1 < ntiles; t += 2) {  // both tests unconditional, so neither load can be sunk next to its use
     pb = tile[(t + 1) * WAVE + lane];
     test_tile(pa, t);
@@ -891,8 +986,27 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
     test_tile(pb, t + 1);
   }
   if (t < ntiles) test_tile(pa, t);
+  if constexpr (VBITS) {
+    uint32_t w[GC], tot[GC];
+#pragma unroll
+    for (int k = 0; k < GC; k++) {
+      w[k] = __brev(~bits[k]) >> (32 - ntiles);  // tile t ended at bit ntiles - 1 - t; the bits above were never written
+      if (NOSELF && lane == ((self0 + k) & (WAVE - 1))) w[k] &= ~(1u << ((self0 + k) >> 6));
+      if (store_masks && !(NL_DIAG & 2)) mask_store(a.masks, (size_t)(slot0 + k) * a.mask_nb + batch, lane, w[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < GC; k += 2) {  // two rows per DPP sum: a row has at most CAP < 2^16 accepted partners per batch
+      const uint32_t two = wave_sum_dpp((uint32_t)__popc(w[k]) | (k + 1 < GC ? (uint32_t)__popc(w[k + 1]) << 16 : 0u));
+      tot[k] = two & 0xffffu;
+      if (k + 1 < GC) tot[k + 1] = two >> 16;
+    }
+    uint32_t mine_v = 0;
+#pragma unroll
+    for (int k = 0; k < GC; k++) mine_v = lane == k ? tot[k] : mine_v;
+    return (int32_t)mine_v;
+  }
   if (MODE == MODE_COUNT_MASKS) {
-    if (store_masks) {
+    if (store_masks && !(NL_DIAG & 2)) {
 #pragma unroll
       for (int k = 0; k < GC; k++) {
         uint32_t w = __brev(bits[k]) >> (32 - ntiles);
@@ -1021,6 +1135,14 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
               : __builtin_amdgcn_readlane(c.seg_off, 13) + ibeg - __builtin_amdgcn_readlane(c.seg_src, 13);
   }
 
+#if NL_STAMP
+  uint64_t t_prev = __builtin_amdgcn_s_memtime(), t_acc[6] = {0, 0, 0, 0, 0, 0}, n_tests = 0;  // wave-uniform: SGPRs
+  auto stamp = [&](int phase) {
+    const uint64_t now = __builtin_amdgcn_s_memtime();
+    t_acc[phase] += now - t_prev;
+    t_prev = now;
+  };
+#endif
   for (int32_t batch = 0; batch < nbatch; batch++) {
     const int32_t win0 = batch * CAP;
     const int32_t nj = min(total_j - win0, CAP);
@@ -1069,8 +1191,13 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
         for (int32_t k = lane; k < len; k += 2 * WAVE) {
           const int32_t k1 = k + WAVE;
           const bool p1 = k1 < len;
+#if NL_DIAG & 4
+          Pos<T> v0, v1;
+          v0.x = (T)k, v0.y = (T)src, v0.z = (T)off, v0.gid = k, v1 = v0;
+#else
           const Pos<T> v0 = a.sorted[src + k];
           const Pos<T> v1 = a.sorted[src + (p1 ? k1 : k)];
+#endif
           if (nbatch == 1 || (uint32_t)(off + k) < (uint32_t)CAP) tile[off + k] = v0;
           if (p1 && (nbatch == 1 || (uint32_t)(off + k1) < (uint32_t)CAP)) tile[off + k1] = v1;
         }
@@ -1099,7 +1226,13 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       for (int d = 32; d > 0; d >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, d, WAVE));
       if (lane == 0) rmax_w[wave] = rmax;
     }
+#if NL_STAMP
+    stamp(1);  // staging: loads issued, LDS written
+#endif
     __syncthreads();
+#if NL_STAMP
+    stamp(2);  // barrier
+#endif
     float rj = 0.f;  // SCREEN: largest L1 norm of a staged particle's relative coordinates
     if constexpr (SCREEN) {
 #pragma unroll
@@ -1169,6 +1302,9 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
           continue;
         }
       }
+#if NL_STAMP
+      stamp(3);  // group prologue (look-ahead loads consumed, next issued)
+#endif
       switch (gcount) {
         case 1: mine = search_group<T, MODE, 1, FULL, false, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch, &sc, uxi, uyi, uzi); break;
         case 2: mine = search_group<T, MODE, 2, FULL, false, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch, &sc, uxi, uyi, uzi); break;
@@ -1176,6 +1312,10 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
         case 4: mine = search_group<T, MODE, 4, FULL, false, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch, &sc, uxi, uyi, uzi); break;
         default: mine = search_group<T, MODE, 5, FULL, false, SCREEN, PBC>(a, tile, nj, ntiles, lane, pi_l, base_l, slot0, keep, 0, batch, &sc, uxi, uyi, uzi); break;
       }
+#if NL_STAMP
+      stamp(4);  // search_group: readlanes, tile loop, mask stores
+      n_tests += (uint64_t)(gcount * ntiles);
+#endif
       if (lane < gcount) {
         if (nbatch > 1) {
           mine += before;
@@ -1183,8 +1323,19 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
         }
         if (MODE != MODE_FILL && batch == nbatch - 1) a.count[row_l] = mine;
       }
+#if NL_STAMP
+      stamp(5);  // count store
+#endif
     }
   }
+#if NL_STAMP
+  if (MODE == MODE_COUNT_MASKS && lane == 0) {  // one set of atomics per wave, spread over 1024 slots (the host sums them)
+    unsigned long long* const slot = a.dbg_buf + 64 + (blockIdx.x & 1023) * 16;
+    for (int ph = 1; ph < 6; ph++) atomicAdd(slot + ph, (unsigned long long)t_acc[ph]);
+    atomicAdd(slot + 8, (unsigned long long)n_tests);
+    atomicAdd(slot + 9, 1ull);
+  }
+#endif
 }
 
 // LDS batch of the sweeps.  (Measured at BASELINE config 5, fp64, 311 particles per cell: half the batch -- 20 KB of
@@ -1206,6 +1357,9 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   CellCtx c;
+#if NL_STAMP
+  const uint64_t t_entry = __builtin_amdgcn_s_memtime();
+#endif
   if (MODE == MODE_COUNT_MASKS || a.isplit <= 1) {
     if (!cell_setup(a, lane, c)) return;
   } else {
@@ -1221,6 +1375,9 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
     c.ibeg += lo, c.ni = hi - lo;
     if (c.ni <= 0) return;
   }
+#if NL_STAMP
+  if (MODE == MODE_COUNT_MASKS && lane == 0) atomicAdd(a.dbg_buf + 64 + (blockIdx.x & 1023) * 16, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_entry));
+#endif
   cell_search<T, MODE, CAP, SWEEP_WAVES, FULL, PBC, SCREEN>(a, c, tile, tid, lane, wave);
 }
 
@@ -1238,6 +1395,9 @@ k_sweep_count_f32(SweepArgs<float> a) {
 }
 template <bool FULL = false, bool PBC = false>
 __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
+#if NL_COUNT_WPE
+__attribute__((amdgpu_waves_per_eu(NL_COUNT_WPE, NL_COUNT_WPE)))
+#endif
 k_sweep_count_masks_f32(SweepArgs<float> a) {
   sweep_cell<float, MODE_COUNT_MASKS, FULL, PBC>(a);
 }

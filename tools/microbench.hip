@@ -122,6 +122,82 @@ __global__ void __launch_bounds__(1024) k(float* out, unsigned long long* stamps
                "v_cmp_nlt_f32 vcc, s46, v40\n v_cndmask_b32 v43, v53, v52, vcc\n v_cmp_lt_i32 vcc, s47, v43\n"
                "v_addc_co_u32 v44, vcc, 0, v44, vcc\n"
                ::: "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "vcc");)
+    } else if (KIND == 40) {
+      REP8(asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                        "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 41) {
+      REP8(asm volatile("v_mul_f32 %0, %8, %0\n v_mul_f32 %1, %8, %1\n v_mul_f32 %2, %8, %2\n v_mul_f32 %3, %8, %3\n"
+                        "v_mul_f32 %4, %8, %4\n v_mul_f32 %5, %8, %5\n v_mul_f32 %6, %8, %6\n v_mul_f32 %7, %8, %7\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sb) : "vcc");)
+    } else if (KIND == 42) {
+      REP8(asm volatile("v_or_b32 %0, %0, %8\n v_or_b32 %1, %1, %8\n v_or_b32 %2, %2, %8\n v_or_b32 %3, %3, %8\n"
+                        "v_or_b32 %4, %4, %8\n v_or_b32 %5, %5, %8\n v_or_b32 %6, %6, %8\n v_or_b32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 43) {
+      REP8(asm volatile("v_lshl_or_b32 %0, %0, 1, %8\n v_lshl_or_b32 %1, %1, 1, %8\n v_lshl_or_b32 %2, %2, 1, %8\n v_lshl_or_b32 %3, %3, 1, %8\n"
+                        "v_lshl_or_b32 %4, %4, 1, %8\n v_lshl_or_b32 %5, %5, 1, %8\n v_lshl_or_b32 %6, %6, 1, %8\n v_lshl_or_b32 %7, %7, 1, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 44) {
+      REP8(asm volatile("v_bfi_b32 %0, %8, %0, %0\n v_bfi_b32 %1, %8, %1, %1\n v_bfi_b32 %2, %8, %2, %2\n v_bfi_b32 %3, %8, %3, %3\n"
+                        "v_bfi_b32 %4, %8, %4, %4\n v_bfi_b32 %5, %8, %5, %5\n v_bfi_b32 %6, %8, %6, %6\n v_bfi_b32 %7, %8, %7, %7\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 45) {
+      REP8(asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc\n v_addc_co_u32 %1, vcc, %1, %1, vcc\n v_addc_co_u32 %2, vcc, %2, %2, vcc\n v_addc_co_u32 %3, vcc, %3, %3, vcc\n"
+                        "v_addc_co_u32 %4, vcc, %4, %4, vcc\n v_addc_co_u32 %5, vcc, %5, %5, vcc\n v_addc_co_u32 %6, vcc, %6, %6, vcc\n v_addc_co_u32 %7, vcc, %7, %7, vcc\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 46) {
+      REP8(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                        "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 47) {
+      REP8(asm volatile("v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
+                        "v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 48) {
+      REP8(asm volatile("v_subrev_u32 %0, %8, %0\n v_subrev_u32 %1, %8, %1\n v_subrev_u32 %2, %8, %2\n v_subrev_u32 %3, %8, %3\n"
+                        "v_subrev_u32 %4, %8, %4\n v_subrev_u32 %5, %8, %5\n v_subrev_u32 %6, %8, %6\n v_subrev_u32 %7, %8, %7\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sb) : "vcc");)
+    } else if (KIND == 49) {
+      REP8(asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n"
+                        "v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 50) {
+      REP8(asm volatile("v_fmac_f32 %0, %8, %8\n v_fmac_f32 %1, %8, %8\n v_fmac_f32 %2, %8, %8\n v_fmac_f32 %3, %8, %8\n"
+                        "v_fmac_f32 %4, %8, %8\n v_fmac_f32 %5, %8, %8\n v_fmac_f32 %6, %8, %8\n v_fmac_f32 %7, %8, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 51) {
+      REP8(asm volatile("v_mul_legacy_f32 %0, %0, %8\n v_mul_legacy_f32 %1, %1, %8\n v_mul_legacy_f32 %2, %2, %8\n v_mul_legacy_f32 %3, %3, %8\n"
+                        "v_mul_legacy_f32 %4, %4, %8\n v_mul_legacy_f32 %5, %5, %8\n v_mul_legacy_f32 %6, %6, %8\n v_mul_legacy_f32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 52) {
+      REP8(asm volatile("v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"
+                        "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sb) : "vcc");)
+    } else if (KIND == 53) {
+      REP8(asm volatile("v_mul_f32 %0, %0, %0\n v_mul_f32 %1, %1, %1\n v_mul_f32 %2, %2, %2\n v_mul_f32 %3, %3, %3\n"
+                        "v_mul_f32 %4, %4, %4\n v_mul_f32 %5, %5, %5\n v_mul_f32 %6, %6, %6\n v_mul_f32 %7, %7, %7\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 54) {
+      REP8(asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                        "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 55) {
+      REP8(asm volatile("v_lshlrev_b32 %0, 1, %0\n v_lshlrev_b32 %1, 1, %1\n v_lshlrev_b32 %2, 1, %2\n v_lshlrev_b32 %3, 1, %3\n"
+                        "v_lshlrev_b32 %4, 1, %4\n v_lshlrev_b32 %5, 1, %5\n v_lshlrev_b32 %6, 1, %6\n v_lshlrev_b32 %7, 1, %7\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 56) {
+      REP8(asm volatile("v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n"
+                        "v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b) : "vcc");)
+    } else if (KIND == 58) {
+      REP8(asm volatile("v_cndmask_b32 %0, %0, %8, %9\n v_cndmask_b32 %1, %1, %8, %9\n v_cndmask_b32 %2, %2, %8, %9\n v_cndmask_b32 %3, %3, %8, %9\n"
+                        "v_cndmask_b32 %4, %4, %8, %9\n v_cndmask_b32 %5, %5, %8, %9\n v_cndmask_b32 %6, %6, %8, %9\n v_cndmask_b32 %7, %7, %8, %9\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "s"(m0) : "vcc");)
+    } else if (KIND == 59) {
+      REP8(asm volatile("v_cndmask_b32 %0, %8, %0, vcc\n v_cndmask_b32 %1, %8, %1, vcc\n v_cndmask_b32 %2, %8, %2, vcc\n v_cndmask_b32 %3, %8, %3, vcc\n"
+                        "v_cndmask_b32 %4, %8, %4, vcc\n v_cndmask_b32 %5, %8, %5, vcc\n v_cndmask_b32 %6, %8, %6, vcc\n v_cndmask_b32 %7, %8, %7, vcc\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "s"(m0) : "vcc");)
     } else if (KIND == 20) {
       REP8(asm volatile("v_alignbit_b32 %0, %0, %8, 31\n v_alignbit_b32 %1, %1, %8, 31\n v_alignbit_b32 %2, %2, %8, 31\n v_alignbit_b32 %3, %3, %8, 31\n"
                         "v_alignbit_b32 %4, %4, %8, 31\n v_alignbit_b32 %5, %5, %8, 31\n v_alignbit_b32 %6, %6, %8, 31\n v_alignbit_b32 %7, %7, %8, 31\n"
@@ -237,6 +313,12 @@ template <int KIND> int run(const char* name, int per_iter, float* out, unsigned
     for (int w = 0; w < nwaves; w++) cyc[w] = (double)st[2 * w];
     std::sort(cyc.begin(), cyc.end());
     printf(" | %dx%d(w%d) %5.2f/%5.2f", bpc, threads, wps, cyc[nwaves / 2] / ((double)iters * per_iter * wps), cyc[nwaves - 1] / ((double)iters * per_iter * wps));
+    if (getenv("MICRO_NS")) {  // the same in nanoseconds (s_memrealtime: 100 MHz) and the s_memtime rate that implies
+      std::vector<double> rt(nwaves);
+      for (int w = 0; w < nwaves; w++) rt[w] = (double)st[2 * w + 1] * 10.0;
+      std::sort(rt.begin(), rt.end());
+      printf(" [%.3f ns, memtime %.0f MHz]", rt[nwaves / 2] / ((double)iters * per_iter * wps), cyc[nwaves / 2] / rt[nwaves / 2] * 1e3);
+    }
   }
   printf("\n");
   return 0;
@@ -251,6 +333,40 @@ int main() {
   CHK(hipGetDeviceProperties(&prop, 0));
   printf("device %s, %d CUs. cycles = shader cycles (s_memtime) per wave-instruction per SIMD, median/max over waves\n",
          prop.gcnArchName, prop.multiProcessorCount);
+  if (getenv("MICRO_OPS")) {  // issue cost of single VALU instructions, 8 independent registers
+    run<0>("v_add_f32 v,v", 64, out, stamps);
+    run<52>("v_add_f32 s,v", 64, out, stamps);
+    run<10>("v_subrev_f32 s,v", 64, out, stamps);
+    run<40>("v_mul_f32 v,v", 64, out, stamps);
+    run<41>("v_mul_f32 s,v", 64, out, stamps);
+    run<53>("v_mul_f32 v,v (square)", 64, out, stamps);
+    run<51>("v_mul_legacy_f32", 64, out, stamps);
+    run<50>("v_fmac_f32 (VOP2)", 64, out, stamps);
+    run<4>("v_fma_f32", 64, out, stamps);
+    run<47>("v_max_f32", 64, out, stamps);
+    run<42>("v_or_b32", 64, out, stamps);
+    run<56>("v_xor_b32", 64, out, stamps);
+    run<21>("v_and_b32", 64, out, stamps);
+    run<54>("v_add_u32", 64, out, stamps);
+    run<22>("v_sub_u32", 64, out, stamps);
+    run<48>("v_subrev_u32 s,v", 64, out, stamps);
+    run<55>("v_lshlrev_b32", 64, out, stamps);
+    run<49>("v_mov_b32", 64, out, stamps);
+    run<20>("v_alignbit_b32", 64, out, stamps);
+    run<43>("v_lshl_or_b32", 64, out, stamps);
+    run<44>("v_bfi_b32", 64, out, stamps);
+    run<45>("v_addc_co_u32 vcc", 64, out, stamps);
+    run<46>("v_cndmask_b32 vcc", 64, out, stamps);
+    run<58>("v_cndmask_b32 sgpr pair", 64, out, stamps);
+    run<59>("v_cndmask_b32 vcc (src swapped)", 64, out, stamps);
+    run<5>("v_cmp_lt_f32 -> vcc", 64, out, stamps);
+    run<6>("v_cmp_lt_f32 -> sgpr pair", 64, out, stamps);
+    run<12>("test body unpacked (10 instr) /test", 8, out, stamps);
+    run<14>("test + s_and,s_bcnt1,s_add /test", 8, out, stamps);
+    run<31>("test + count + mask bits /test", 8, out, stamps);
+    run<30>("test + sign-bit tail (12 VALU, 0 SALU) /test", 8, out, stamps);
+    return 0;
+  }
   if (getenv("MICRO_TAIL")) {  // which hit-recording tail for the VALU sweep
     run<12>("test body unpacked (10 instr) /test", 8, out, stamps);
     run<14>("test + s_and,s_bcnt1,s_add /test", 8, out, stamps);
