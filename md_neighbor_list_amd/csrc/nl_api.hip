@@ -27,6 +27,7 @@ struct HostResult {
 };
 constexpr int META_TOTAL = 18;  // int32 offset of total_lo from the status word
 constexpr int META_FULL27 = 1;  // number of cells the half-shell path hands to the 27-cell search (first "ticket" word)
+constexpr int META_PIPE = 2;    // 8 chunk-ticket counters of the pipelined COUNT sweep, one per XCD ("ticket" words 2..9)
 constexpr int META_WORDS = 20;
 
 }  // namespace
@@ -81,6 +82,7 @@ struct nl_handle_s {
   size_t masks_bytes = 0;          // size of the masks allocation
   int32_t b_isplit = 1;            // this build, two-sweep path: workgroups per cell
   int isplit_env = 0;              // NL_ISPLIT: 0 = by density
+  int pipe_wg_per_cu = 0;          // NL_PIPE: workgroups per CU of the pipelined COUNT sweep (k_sweep_pipe_f32); 0 = one workgroup per cell
   bool dense_masks_off = false;    // NL_DENSE_MASKS=0: dense builds use two distance sweeps (the round-1 path)
   size_t dense_masks_limit = (size_t)64 << 30;  // most memory the mask rows of a dense build may take
   int half_cpb = 4;                // cells a workgroup of k_sweep_half walks (NL_HALF_CPB)
@@ -269,6 +271,7 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.mask_nb = h->b_mask_nb;
   a.full27_list = h->full27_list;
   a.full27_count = reinterpret_cast<int32_t*>(h->status) + META_FULL27;
+  a.pipe_ticket = reinterpret_cast<int32_t*>(h->status) + META_PIPE;
   a.pbc = h->pbc ? 1 : 0;
   for (int d = 0; d < 3; d++) a.ms[d] = (T)(h->L[d] / h->m[d]);
   for (int d = 0; d < 3; d++) a.L[d] = (T)h->L[d];
@@ -329,9 +332,21 @@ template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h,
   }
   if (h->b_use_masks) {
     if (mode == MODE_COUNT) {
-      if constexpr (sizeof(T) == 4)
-        hipLaunchKernelGGL((k_sweep_count_masks_f32<FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), h->dbg_lds_pad, s, a);
-      else
+      if constexpr (sizeof(T) == 4) {
+        if (!PBC && h->b_mask_nb == 1 && h->pipe_wg_per_cu > 0) {
+          // persistent workgroups, each a software pipeline over a run of consecutive cells (nl_pipe.hpp)
+          SweepArgs<T> ap = a;
+          ap.ncells_grid = ncells_i;
+          const int32_t grid = std::max(1, std::min(ncells_i, h->pipe_wg_per_cu * h->num_cus));
+          if (h->pipe_wg_per_cu >= 8)  // NL_PIPE >= 8: single-buffer persistent workgroups of 4 waves
+            hipLaunchKernelGGL((k_sweep_persist_f32<FULL>), dim3(grid), dim3(PERSIST_WAVES * WAVE), 0, s, ap);
+          else
+            hipLaunchKernelGGL((k_sweep_pipe_f32<FULL>), dim3(grid), dim3(PIPE_WAVES * WAVE), 0, s, ap);
+          hipLaunchKernelGGL((k_sweep_list_f32<FULL>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ap);
+        } else {
+          hipLaunchKernelGGL((k_sweep_count_masks_f32<FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), h->dbg_lds_pad, s, a);
+        }
+      } else
         hipLaunchKernelGGL((k_sweep<T, MODE_COUNT_MASKS, FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
     } else if (h->b_wide) {
       launch_fill_masks<T, FULL, PBC, int64_t>(h, a, ncells_i, s);
@@ -771,6 +786,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
     if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : atoi(v) >= 6 ? 6 : atoi(v) == 5 ? 5 : 3;
     if (const char* v = getenv("NL_ISPLIT")) h->isplit_env = std::max(0, atoi(v));
+    if (const char* v = getenv("NL_PIPE")) h->pipe_wg_per_cu = std::max(0, std::min(atoi(v), 64));
     if (const char* v = getenv("NL_DENSE_MASKS")) h->dense_masks_off = atoi(v) == 0;
     if (const char* v = getenv("NL_HALF_CPB")) h->half_cpb = std::max(1, atoi(v));
     if (const char* v = getenv("NL_OFFSET_WIDTH")) h->offset_width = atoi(v) == 64 ? 64 : atoi(v) == 32 ? 32 : 0;
@@ -847,8 +863,9 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
     if ((rc = dev_alloc(h, &h->rmask, 8 * (size_t)HS_NUP * (size_t)h->rstride))) return rc;
     if ((rc = dev_alloc(h, &h->fcnt, 4 * (n + 16)))) return rc;
     if ((rc = dev_alloc(h, &h->rcnt, (size_t)HS_NUP * (size_t)h->rstride))) return rc;
-    if ((rc = dev_alloc(h, &h->full27_list, 4 * ((size_t)h->ncell + 16)))) return rc;
   }
+  // cells handed from one search kernel to another: half-shell -> 27-cell search, pipelined COUNT -> batched search
+  if ((rc = dev_alloc(h, &h->full27_list, 4 * ((size_t)h->ncell + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->dbg_buf, 8 * (64 + 4 * 4096)))) return rc;
   HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
   if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64 + 2 * (size_t)h->m[1] * h->m[2])))) return rc;

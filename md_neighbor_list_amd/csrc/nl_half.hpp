@@ -177,6 +177,9 @@ __device__ __forceinline__ int32_t search_group_half(const SweepArgs<T>& a, cons
   const int32_t last = (ntiles - 1) * WAVE + lane;
   Pos<T> pa = tile[lane], pb;
   int32_t t = 0;
+#if NL_PRIO
+  __builtin_amdgcn_s_setprio(0);  // (as search_group: the tile loop yields to waves that are setting up, staging, storing)
+#endif
   for (; t + 1 < ntiles; t += 2) {
     pb = tile[(t + 1) * WAVE + lane];
     test_tile(pa, t);
@@ -184,6 +187,9 @@ __device__ __forceinline__ int32_t search_group_half(const SweepArgs<T>& a, cons
     test_tile(pb, t + 1);
   }
   if (t < ntiles) test_tile(pa, t);
+#if NL_PRIO
+  __builtin_amdgcn_s_setprio(NL_PRIO);
+#endif
   if (write_f) {
 #pragma unroll
     for (int k = 0; k < GC; k++) {
@@ -260,6 +266,9 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE, (sizeof(T) == 4 ? 7 : 4)) k
   __shared__ unsigned long long rw[HS_CAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NPRE = (HS_NSEG + SWEEP_WAVES - 1) / SWEEP_WAVES;  // segments per wave: wave, wave + 4, ...
+#if NL_PRIO
+  __builtin_amdgcn_s_setprio(NL_PRIO);
+#endif
   const uint32_t st_word = *a.status;  // (read with the first cell table)
   const int32_t w0 = xcd_cell_index() * a.cells_per_block, w1 = min(w0 + a.cells_per_block, a.ncells_grid);
   // diagnostics (NL_DEBUG_FLAGS & 4, tools/half_phases.py): shader cycles of every wave per phase, summed into dbg_buf[8 + phase]

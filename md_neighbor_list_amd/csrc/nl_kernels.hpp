@@ -708,6 +708,7 @@ template <typename T> struct SweepArgs {
   int32_t mask_nb;                         // mask rows per sorted slot: 1, or up to FD_NB LDS batches in a dense build
   int32_t* __restrict__ full27_list;       // local cell indices of the cells k_full27 builds (irregular stencil)
   int32_t* __restrict__ full27_count;      // their number: a meta word next to the status word, zeroed with it
+  int32_t* __restrict__ pipe_ticket;       // [8] k_sweep_pipe_f32: chunk tickets, one counter per XCD (meta words, zeroed per build)
   uint32_t* __restrict__ masks;  // [n] rows of 64 x 24 bits (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
   int32_t dbg;  // diagnostics only (NL_DEBUG_FLAGS): 1 = skip the search, 2 = skip the staging copy; 0 in production
@@ -761,6 +762,12 @@ template <typename T> struct TileOf<T, true> { typedef PosS type; };
 #endif
 #ifndef NL_VBITS_SPLIT
 #define NL_VBITS_SPLIT 1
+#endif
+#ifndef NL_STAGE_DMA
+#define NL_STAGE_DMA 1
+#endif
+#ifndef NL_PRIO  // wave priority outside the tile loop of the COUNT_MASKS sweeps (0: leave it alone)
+#define NL_PRIO 3
 #endif
 #ifndef NL_PKMUL
 #define NL_PKMUL 0
@@ -820,7 +827,8 @@ template <typename T, int MODE, int GC, bool FULL = false, bool NOSELF = false, 
 __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typename TileOf<T, SCREEN>::type* tile, int32_t nj,
                                                 int32_t ntiles, int lane, const Pos<T>& pi_l, int64_t base_l,
                                                 int32_t slot0 = 0, bool store_masks = false, int32_t self0 = 0, int32_t batch = 0,
-                                                const ScreenCtx* sc = nullptr, float uxi_l = 0.f, float uyi_l = 0.f, float uzi_l = 0.f) {
+                                                const ScreenCtx* sc = nullptr, float uxi_l = 0.f, float uyi_l = 0.f, float uzi_l = 0.f,
+                                                uint32_t* words_out = nullptr) {
   static_assert(!NOSELF || (FULL && MODE == MODE_COUNT_MASKS), "NOSELF is a form of the full-list COUNT_MASKS search");
   static_assert(SweepCfg<T>::CAP / WAVE <= 24, "one bit per j-tile in the 24-bit word a lane keeps (mask_store)");
   static_assert(!SCREEN || sizeof(T) == 8, "the screened search is the fp64 search");
@@ -979,6 +987,9 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   const int32_t last = (ntiles - 1) * WAVE + lane;
   TileT pa = tile[lane], pb;
   int32_t t = (NL_DIAG & 1) ? ntiles : 0;
+#if NL_PRIO
+  if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(0);  // the tile loop yields to waves that are setting up, staging, storing
+#endif
   for (; t + 1 < ntiles; t += 2) {  // both tests unconditional, so neither load can be sunk next to its use
     pb = tile[(t + 1) * WAVE + lane];
     test_tile(pa, t);
@@ -986,13 +997,17 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
     test_tile(pb, t + 1);
   }
   if (t < ntiles) test_tile(pa, t);
+#if NL_PRIO
+  if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(NL_PRIO);
+#endif
   if constexpr (VBITS) {
     uint32_t w[GC], tot[GC];
 #pragma unroll
     for (int k = 0; k < GC; k++) {
       w[k] = __brev(~bits[k]) >> (32 - ntiles);  // tile t ended at bit ntiles - 1 - t; the bits above were never written
       if (NOSELF && lane == ((self0 + k) & (WAVE - 1))) w[k] &= ~(1u << ((self0 + k) >> 6));
-      if (store_masks && !(NL_DIAG & 2)) mask_store(a.masks, (size_t)(slot0 + k) * a.mask_nb + batch, lane, w[k]);
+      if (words_out) words_out[k] = w[k];  // (k_sweep_pipe_f32: the caller stores the words later)
+      else if (store_masks && !(NL_DIAG & 2)) mask_store(a.masks, (size_t)(slot0 + k) * a.mask_nb + batch, lane, w[k]);
     }
 #pragma unroll
     for (int k = 0; k < GC; k += 2) {  // two rows per DPP sum: a row has at most CAP < 2^16 accepted partners per batch
@@ -1052,6 +1067,38 @@ template <typename T> __device__ __forceinline__ bool cell_setup(const SweepArgs
   return cell_setup_at(a, lane, cx, cy, cz, c);
 }
 
+// Segment `lane` (< NSEG) of the stencil stream of cell (cx, cy, cz; cz: local layer): the cells [i0, i1) of the
+// cell-sorted array, as indices into cell_start, and through which periodic faces they are reached (CellCtx::wrap).
+// One segment per lane: 9 (dz,dy) rows x 2 x-parts; slots 0..8 = first x-part of the nine rows (never empty in the
+// interior), 9..17 = the part behind the periodic wrap in x (empty unless cx is 0 or mx - 1).
+template <typename T>
+__device__ __forceinline__ void segment_cells(const SweepArgs<T>& a, int lane, int32_t cx, int32_t cy, int32_t cz,
+                                              int32_t& i0, int32_t& i1, int32_t& wrap) {
+  const int32_t s = lane % 9, part = lane / 9, dz = s / 3 - 1, dy = s % 3 - 1;
+  int32_t y = cy + dy, z = cz + dz;
+  if (y < 0) y += a.my;
+  if (y >= a.my) y -= a.my;
+  if (!a.slab) {
+    if (z < 0) z += a.mzl;
+    if (z >= a.mzl) z -= a.mzl;
+  }
+  int32_t x0, x1;  // cells [x0, x1) of that row
+  if (cx == 0) {
+    x0 = part ? 0 : a.mx - 1, x1 = part ? 2 : a.mx;
+  } else if (cx == a.mx - 1) {
+    x0 = part ? 0 : a.mx - 2, x1 = part ? 1 : a.mx;
+  } else {
+    x0 = cx - 1, x1 = part ? cx - 1 : cx + 2;
+  }
+  const int32_t rowbase = (y + z * a.my) * a.mx;
+  i0 = rowbase + x0, i1 = rowbase + x1;
+  // through which periodic faces this segment is reached (used in minimum-image mode only)
+  const int32_t wx = (cx == 0 && part == 0) ? -1 : (cx == a.mx - 1 && part == 1) ? 1 : 0;
+  const int32_t wy = cy + dy < 0 ? -1 : cy + dy >= a.my ? 1 : 0;
+  const int32_t wz = a.slab ? 0 : cz + dz < 0 ? -1 : cz + dz >= a.mzl ? 1 : 0;
+  wrap = (wx + 1) | (wy + 1) << 2 | (wz + 1) << 4;
+}
+
 // The segment table of the i-cell (cx, cy, cz): cz is the local layer.
 template <typename T> __device__ __forceinline__ bool cell_setup_at(const SweepArgs<T>& a, int lane, int32_t cx, int32_t cy, int32_t cz, CellCtx& c) {
   const int32_t cell = cx + (cy + cz * a.my) * a.mx;
@@ -1064,34 +1111,12 @@ template <typename T> __device__ __forceinline__ bool cell_setup_at(const SweepA
   c.cx = cx, c.cy = cy, c.cz = cz;
 
   // (the empty-cell exit comes after the segment-table loads so that both round trips are in flight together)
-  // Segment table, one segment per lane (lanes >= 18 hold empty segments): 9 (dz,dy) rows x 2 x-parts.
   c.seg_src = 0, c.seg_len = 0, c.wrap = 0x15;
   if (lane < NSEG) {
-    // slots 0..8 = first x-part of the nine (dz,dy) rows (never empty in the interior), 9..17 = the wrapped part
-    const int32_t s = lane % 9, part = lane / 9, dz = s / 3 - 1, dy = s % 3 - 1;
-    int32_t y = cy + dy, z = cz + dz;
-    if (y < 0) y += a.my;
-    if (y >= a.my) y -= a.my;
-    if (!a.slab) {
-      if (z < 0) z += a.mzl;
-      if (z >= a.mzl) z -= a.mzl;
-    }
-    int32_t x0, x1;  // cells [x0, x1) of that row
-    if (cx == 0) {
-      x0 = part ? 0 : a.mx - 1, x1 = part ? 2 : a.mx;
-    } else if (cx == a.mx - 1) {
-      x0 = part ? 0 : a.mx - 2, x1 = part ? 1 : a.mx;
-    } else {
-      x0 = cx - 1, x1 = part ? cx - 1 : cx + 2;
-    }
-    const int32_t rowbase = (y + z * a.my) * a.mx;
-    c.seg_src = a.cell_start[rowbase + x0];
-    c.seg_len = a.cell_start[rowbase + x1] - c.seg_src;
-    // through which periodic faces this segment is reached (used in minimum-image mode only)
-    const int32_t wx = (cx == 0 && part == 0) ? -1 : (cx == a.mx - 1 && part == 1) ? 1 : 0;
-    const int32_t wy = cy + dy < 0 ? -1 : cy + dy >= a.my ? 1 : 0;
-    const int32_t wz = a.slab ? 0 : cz + dz < 0 ? -1 : cz + dz >= a.mzl ? 1 : 0;
-    c.wrap = (wx + 1) | (wy + 1) << 2 | (wz + 1) << 4;
+    int32_t i0, i1;
+    segment_cells(a, lane, cx, cy, cz, i0, i1, c.wrap);
+    c.seg_src = a.cell_start[i0];
+    c.seg_len = a.cell_start[i1] - c.seg_src;
   }
   if (c.ni <= 0 || (st_word & ST_DOMAIN)) return false;
   c.seg_off = scan32_dpp(c.seg_len) - c.seg_len;  // exclusive offsets in the staged stream
@@ -1155,9 +1180,23 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
     // the compiler waits for every load before it issues the next, 4-6 dependent round trips per wave and cell, and the
     // kernel is the faster for it.  profiles/r02_count_staging_ab.txt)
     float rmax = 0.f;  // SCREEN: largest L1 norm of the relative coordinates this thread stages
+    constexpr bool DMA = NL_STAGE_DMA && sizeof(T) == 4 && !PBC && !SCREEN && MODE == MODE_COUNT_MASKS;
     for (int32_t sg = wave; sg < NSEG; sg += NW) {
       const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
       if (len == 0) continue;
+      if constexpr (DMA) {
+        if (nbatch == 1) {  // (uniform) the whole stream in one batch: LDS-DMA, 16 bytes per lane, no registers, every
+          // piece in flight until the barrier below
+          const int32_t src1 = __builtin_amdgcn_readlane(c.seg_src, sg), off1 = __builtin_amdgcn_readlane(c.seg_off, sg);
+#pragma unroll 1
+          for (int32_t kb = 0; kb < len; kb += WAVE) {
+            if (kb + lane < len)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.sorted + src1 + kb + lane),
+                                               (__attribute__((address_space(3))) void*)(tile + off1 + kb), 16, 0, 0);
+          }
+          continue;
+        }
+      }
       const int32_t src = __builtin_amdgcn_readlane(c.seg_src, sg);
       const int32_t off = __builtin_amdgcn_readlane(c.seg_off, sg) - win0;
       // minimum-image kernels (PBC): a segment reached through a periodic face is staged at its image.  Uniform per
@@ -1357,6 +1396,9 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   CellCtx c;
+#if NL_PRIO
+  if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(NL_PRIO);
+#endif
 #if NL_STAMP
   const uint64_t t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -1697,6 +1739,7 @@ __global__ void __launch_bounds__(FD_WAVES* WAVE) k_fill_dense(SweepArgs<T> a, c
 }  // namespace nl
 
 #include "nl_half.hpp"
+#include "nl_pipe.hpp"
 
 namespace nl {
 

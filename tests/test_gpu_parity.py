@@ -958,3 +958,37 @@ def test_resort_then_rebuild_equals_the_oracle_on_the_permuted_input(dtype):
         pairs = np.unique(np.minimum(a, b) * n + np.maximum(a, b))
         assert np.array_equal(pairs, pairs0)
         # a second round re-sorts an already sorted system: the order is the identity up to ties inside a cell
+
+
+@pytest.mark.parametrize("pipe", [4, 8])
+def test_persistent_count_sweeps(pipe, monkeypatch):
+    """NL_PIPE (opt-in): the COUNT_MASKS sweep by persistent workgroups that walk chunks of cells -- 4: 8 waves, the next
+    cell's stream arriving by LDS-DMA during the search (k_sweep_pipe_f32); 8: 4 waves, one buffer
+    (k_sweep_persist_f32).  Same lists as the default kernels: half and full list, a box whose cluster puts cells on the
+    hand-over list of the batched search (k_sweep_list_f32), boxes with fewer chunks than workgroups."""
+    import torch
+
+    from md_neighbor_list_amd import NeighListGPU
+
+    monkeypatch.setenv("NL_PIPE", str(pipe))
+    rng = np.random.default_rng(5 + pipe)
+    cases = [(50000, (36.84, 36.84, 36.84), 3.3, 0.0), (9000, (25.0, 14.0, 19.0), 3.1, 0.0), (4096, (16.0, 16.0, 16.0), 3.3, 0.0),
+             (60000, (40.0, 40.0, 40.0), 3.3, 0.12), (120000, (50.0, 60.0, 45.0), 3.0, 0.02)]
+    for n, box, rc, clustered in cases:
+        q, box = inputs.uniform_box(n, dtype=np.float32, seed=int(rng.integers(1 << 30)), box=box)
+        if clustered:  # part of the particles into two cells' worth of volume: streams of several LDS batches there
+            k = int(clustered * n)
+            q[:k, :3] = (np.array(box) * 0.5 + rng.uniform(-0.9 * rc, 0.9 * rc, size=(k, 3))).astype(np.float32)
+        ref = _po().build(q, rc, box)
+        nl, nop, kp, sl = gpu_build(q, rc, box)
+        assert int(kp[-1]) == ref.npairs, (n, clustered)
+        assert np.array_equal(nop, ref.number_of_partners), (n, clustered)
+        assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), (n, clustered)
+        assert nl.list_checksum() == (ref.hash(), ref.npairs)
+        # the full list on the same handle
+        nl.set_full_list(True)
+        nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+        want_kp, want_list, want_cnt = _full_from_half(ref)
+        fkp, flst, fcnt = (t.cpu().numpy() for t in nl.full_csr())
+        assert np.array_equal(fcnt, want_cnt) and np.array_equal(fkp.astype(np.int64), want_kp), (n, clustered)
+        assert np.array_equal(canonical_csr(fkp, flst), want_list), (n, clustered)
