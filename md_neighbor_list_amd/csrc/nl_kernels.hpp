@@ -718,6 +718,8 @@ template <typename T> struct SweepCfg;
 // Hit masks in memory: one row of 64 x 24 bits per sorted slot (lane l's word at byte 3 l of the 192-byte row; a
 // staged stream has at most CAP / 64 = 20 tiles).  The expansion kernel is bound by what it reads, so the unused
 // byte of a 32-bit word per lane is not stored.  Unaligned accesses: the compiler picks what the target allows.
+// (Measured again in round 2 with aligned 256-byte rows, one dword store and load per lane: COUNT -0.5 %, expansion +4 % at
+// cfg 2; both a few per cent better at cfg 3.  The headline configuration decides.)
 constexpr int MASK_ROW_BYTES = 192;
 struct __attribute__((packed)) MaskU16 { uint16_t v; };
 struct __attribute__((packed)) MaskU32 { uint32_t v; };
@@ -1130,6 +1132,8 @@ constexpr int screen_lds_bytes(int cap) { return cap * 21 + 32; }
 template <typename T, int MODE, int CAP = SweepCfg<T>::CAP, int NW = SWEEP_WAVES, bool FULL = false, bool PBC = false, bool SCREEN = false>
 __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx& c, Pos<T>* tile_raw, int tid, int lane,
                                             int wave) {
+  // (Groups of up to 7 in the fp32 COUNT_MASKS sweeps -- a cell of 41..56 particles in 8 passes over the stream instead
+  // of 12 -- measured level with 5: 0.2779 against 0.2768 ms at cfg 2.)
   constexpr int G = SWEEP_G;
   static_assert(G == 5, "search_group dispatch covers group sizes 1..5");
   typedef typename TileOf<T, SCREEN>::type TileT;
@@ -1148,7 +1152,8 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
   // i-groups: `rounds` groups per wave, sized so that all waves get the same number of groups.
   const int32_t rounds = (ni + NW * G - 1) / (NW * G);
   const int32_t ngroups = rounds * NW;
-  const int32_t gsize = (ni + ngroups - 1) / ngroups;
+  const int32_t gbase = ni / ngroups, grem = ni - gbase * ngroups;  // group g: gbase (+ 1 if g < grem) particles
+  auto group_begin = [&](int32_t g) { return g * gbase + min(g, grem); };
 
   // where the cell's own particles sit in the stream (NOSELF): in the (dz,dy) = (0,0) row, first or wrapped x-part
   int32_t own = 0;
@@ -1287,7 +1292,7 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
     int32_t pre_row = 0, pre_prog = 0;
     int64_t pre_base = 0;
     auto fetch_group = [&](int32_t g) {
-      const int32_t idx = ibeg + min(g * gsize + lane, ni - 1);
+      const int32_t idx = ibeg + min(group_begin(g) + lane, ni - 1);
       pre_p = a.sorted[idx];
       pre_row = a.sorted_row[idx];
       if (MODE == MODE_FILL)
@@ -1297,8 +1302,8 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
     const bool ahead = !(a.dbg & 1024);  // diagnostics: 1024 = every group fetches its own data when it starts
     if (wave < ngroups && ahead) fetch_group(wave);
     for (int32_t g = wave; g < ngroups; g += NW) {
-      const int32_t i0 = g * gsize;
-      const int32_t gcount = min(gsize, ni - i0);  // wave-uniform; may be <= 0 for the last groups
+      const int32_t i0 = group_begin(g);
+      const int32_t gcount = gbase + (g < grem ? 1 : 0);  // wave-uniform; 0 for the last groups of a small cell
       if (gcount <= 0) break;
       // lane k < gcount holds i-particle k of the group
       if (!ahead) fetch_group(g);
@@ -1306,7 +1311,7 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
       const int32_t row_l = pre_row, before = pre_prog;
       int64_t base_l = pre_base + before;
       if (lane >= gcount) pi_l.x = 0, pi_l.y = 0, pi_l.z = 0, pi_l.gid = 0;
-      if (ahead && g + NW < ngroups && (g + NW) * gsize < ni) fetch_group(g + NW);
+      if (ahead && g + NW < ngroups && group_begin(g + NW) < ni) fetch_group(g + NW);
       const int32_t slot0 = ibeg + i0;
       // SCREEN: the i-particles relative to the cell centre, as floats, and the band of this group against this batch
       float uxi = 0.f, uyi = 0.f, uzi = 0.f;
