@@ -715,22 +715,20 @@ template <typename T> struct SweepArgs {
 };
 
 template <typename T> struct SweepCfg;
-// Hit masks in memory: one row of 64 x 24 bits per sorted slot (lane l's word at byte 3 l of the 192-byte row; a
-// staged stream has at most CAP / 64 = 20 tiles).  The expansion kernel is bound by what it reads, so the unused
-// byte of a 32-bit word per lane is not stored.  Unaligned accesses: the compiler picks what the target allows.
-// (Measured again in round 2 with aligned 256-byte rows, one dword store and load per lane: COUNT -0.5 %, expansion +4 % at
-// cfg 2; both a few per cent better at cfg 3.  The headline configuration decides.)
+// Hit masks in memory: one row of 64 x 24 bits per sorted slot (a staged stream has at most CAP / 64 = 20 tiles), 192
+// bytes: the low 16 bits of the 64 lanes, then their high 8 bits -- every store and load naturally aligned and
+// consecutive over the lanes.  (Round 2 measurements at cfg 2 / cfg 3: 3-byte words back to back, lane l at byte 3 l,
+// with unaligned accesses: build +0.5 % / +1 %; aligned 256-byte rows, one dword per lane: COUNT -0.5 % / -2 %,
+// expansion +4 % / -5 % -- the expansion is bound by what it reads.)
 constexpr int MASK_ROW_BYTES = 192;
-struct __attribute__((packed)) MaskU16 { uint16_t v; };
-struct __attribute__((packed)) MaskU32 { uint32_t v; };
 __device__ __forceinline__ void mask_store(uint32_t* masks, size_t slot, int lane, uint32_t bits) {
-  char* const p = reinterpret_cast<char*>(masks) + slot * MASK_ROW_BYTES + 3 * lane;
-  reinterpret_cast<MaskU16*>(p)->v = (uint16_t)bits;
-  *reinterpret_cast<uint8_t*>(p + 2) = (uint8_t)(bits >> 16);
+  char* const row = reinterpret_cast<char*>(masks) + slot * MASK_ROW_BYTES;
+  reinterpret_cast<uint16_t*>(row)[lane] = (uint16_t)bits;
+  reinterpret_cast<uint8_t*>(row + 2 * WAVE)[lane] = (uint8_t)(bits >> 16);
 }
-__device__ __forceinline__ uint32_t mask_load(const uint32_t* masks, size_t slot, int lane) {  // high byte: the next lane's
-  const char* const p = reinterpret_cast<const char*>(masks) + slot * MASK_ROW_BYTES + 3 * lane;
-  return reinterpret_cast<const MaskU32*>(p)->v;
+__device__ __forceinline__ uint32_t mask_load(const uint32_t* masks, size_t slot, int lane) {
+  const char* const row = reinterpret_cast<const char*>(masks) + slot * MASK_ROW_BYTES;
+  return (uint32_t)reinterpret_cast<const uint16_t*>(row)[lane] | (uint32_t)reinterpret_cast<const uint8_t*>(row + 2 * WAVE)[lane] << 16;
 }
 template <> struct SweepCfg<float> { static constexpr int CAP = 1280; };   // 20 KB of LDS: 8 workgroups = 32 waves per CU
 template <> struct SweepCfg<double> { static constexpr int CAP = 1280; };  // 40 KB of LDS (registers, not LDS, limit fp64 occupancy)
@@ -779,6 +777,9 @@ template <typename T> struct TileOf<T, true> { typedef PosS type; };
 #endif
 #ifndef NL_STAMP  // timing experiments only: per-phase wave cycles of the COUNT_MASKS sweep into dbg_buf[16..] (tools/count_phases.py)
 #define NL_STAMP 0
+#endif
+#ifndef NL_STAMP_FILL  // the same for k_fill_masks (tools/fill_phases.py); not together with NL_STAMP
+#define NL_STAMP_FILL 0
 #endif
 #ifndef NL_DIAG  // timing experiments only (wrong lists): 1 = no tile tests, 2 = no mask stores, 4 = no staging loads
 #define NL_DIAG 0
@@ -1484,9 +1485,20 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
   __shared__ __attribute__((aligned(32))) int32_t lds[CAP + EW * 4 * EXPAND_RMAX];
   int32_t* const gids = lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if NL_STAMP_FILL
+  uint64_t ft_prev = __builtin_amdgcn_s_memtime(), ft_acc[6] = {0, 0, 0, 0, 0, 0};
+  auto fstamp = [&](int phase) {
+    const uint64_t now = __builtin_amdgcn_s_memtime();
+    ft_acc[phase] += now - ft_prev;
+    ft_prev = now;
+  };
+#endif
   const int64_t total = a.total[0];  // read together with the cell table: one round trip, not two
   CellCtx c;
   const bool ok = cell_setup(a, lane, c);
+#if NL_STAMP_FILL
+  fstamp(0);
+#endif
   if (total > a.capacity) {  // the list is too small: the host grows it and runs this kernel again
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, ST_CAPACITY);
     return;
@@ -1512,7 +1524,14 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const int32_t slot = c.ibeg + min(r0 + u, c.ni - 1);
+#if NL_DIAG & 8  // timing experiment: no mask loads (one bit per lane instead: 64 entries per row)
+      {  // ~1.06 random bits of 17 per lane: the bit loops see the real distribution
+        uint32_t h1 = (uint32_t)(slot * 64 + lane) * 2654435761u, h2 = h1 * 2246822519u + 374761393u;
+        w[u] = (h1 >> 3) & (h1 >> 15) & (h2 >> 2) & (h2 >> 14) & 0x1FFFFu;
+      }
+#else
       w[u] = mask_load(a.masks, (size_t)slot * a.mask_nb, lane);
+#endif
       base[u] = base_sorted[slot];  // (k_row_base: one gather kernel is cheaper than two dependent loads here)
     }
   };
@@ -1535,7 +1554,13 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
                                          (__attribute__((address_space(3))) void*)(gids + off + kb), 4, 0, 0);
     }
   }
+#if NL_STAMP_FILL
+  fstamp(1);  // row loads and id DMA issued
+#endif
   __syncthreads();  // ids staged
+#if NL_STAMP_FILL
+  fstamp(2);  // barrier (DMA landed)
+#endif
 
   const int32_t* const g = gids + lane;
   for (int32_t r0 = r_beg; r0 < r_end; r0 += RB) {
@@ -1557,6 +1582,9 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
         ptr[q] = (uint32_t)(incl - cnt);  // place inside the row
       }
       const int32_t nmax = max(max(nrow[0], nrow[1]), max(nrow[2], nrow[3]));
+#if NL_STAMP_FILL
+      fstamp(3);  // words arrived, popcounts, scans
+#endif
       if (nmax <= EXPAND_RMAX) {
         // The set bits of a lane are consecutive entries of the row, but one trip through the bit loop writes one
         // entry per lane: ~13 lanes spread over the whole 290-byte row, 5-6 trips per row (8 for a full list).  So
@@ -1583,6 +1611,9 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
             }
           }
         }
+#if NL_STAMP_FILL
+        fstamp(4);  // bit loop
+#endif
         __builtin_amdgcn_wave_barrier();  // the buffer is private to the wave: LDS executes its accesses in order
         for (int32_t e = lane; e - lane < nmax; e += WAVE) {
           int32_t val[4];
@@ -1593,6 +1624,9 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
             if (e < nrow[q]) a.list[(size_t)base[u0 + q] + e] = val[q];
         }
         __builtin_amdgcn_wave_barrier();
+#if NL_STAMP_FILL
+        fstamp(5);  // rows read back and stored
+#endif
         continue;
       }
       while (word[0] | word[1] | word[2] | word[3]) {  // a very long row: straight to memory
@@ -1615,6 +1649,13 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
       }
     }
   }
+#if NL_STAMP_FILL
+  if (lane == 0) {
+    unsigned long long* const slot = a.dbg_buf + 64 + (blockIdx.x & 1023) * 16;
+    for (int ph = 0; ph < 6; ph++) atomicAdd(slot + ph, (unsigned long long)ft_acc[ph]);
+    atomicAdd(slot + 9, 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------- list from masks, dense cells
