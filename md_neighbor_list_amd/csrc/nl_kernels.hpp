@@ -751,6 +751,7 @@ struct alignas(16) PosS {
 };
 struct ScreenCtx {
   float lo, hi;               // r2f < lo: in range; r2f > hi: out of range; else exact test
+  float lo_in, hi_out;        // the same two tests as sign bits: lo_in - r2f >= 0 <=> r2f < lo, r2f - hi_out >= 0 <=> r2f > hi
   const int32_t* sidx;        // [batch slots] sorted-array index of every staged particle (exact coordinates)
   const uint8_t* swrap;       // [batch slots] periodic-face code of its segment (minimum-image mode)
 };
@@ -768,6 +769,9 @@ template <typename T> struct TileOf<T, true> { typedef PosS type; };
 #endif
 #ifndef NL_PRIO  // wave priority outside the tile loop of the COUNT_MASKS sweeps (0: leave it alone)
 #define NL_PRIO 3
+#endif
+#ifndef NL_VBITS_SCREEN
+#define NL_VBITS_SCREEN 1
 #endif
 #ifndef NL_PKMUL
 #define NL_PKMUL 0
@@ -849,7 +853,12 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   // instructions per test where two v_cmp (SGPR-pair results), an s_and, an add-with-carry, an s_bcnt1 and an s_add
   // were -- and no VALU -> SALU -> VALU dependency inside a tile.  The word collects NOT-accepted bits; inverted, and
   // the row counted from it (popcount + one DPP sum per i-particle), after the last tile.
-  constexpr bool VBITS = NL_VBITS && MODE == MODE_COUNT_MASKS && !SCREEN && sizeof(T) == 4 && (!FULL || NOSELF);
+  constexpr bool VBITS_F32 = NL_VBITS && MODE == MODE_COUNT_MASKS && !SCREEN && sizeof(T) == 4 && (!FULL || NOSELF);
+  // The screened fp64 search in the same form: lo_in - r2f and r2f - hi_out carry "decided in range" / "decided out of
+  // range" in their sign bits, the AND of the two over a tile's tests says whether any pair needs the exact expression
+  // (ONE compare and branch per tile), and the exact answer then clears the bit the screen put into the word.
+  constexpr bool VBITS_SCREEN = NL_VBITS && NL_VBITS_SCREEN && MODE == MODE_COUNT_MASKS && SCREEN && (!FULL || NOSELF);
+  constexpr bool VBITS = VBITS_F32 || VBITS_SCREEN;
   uint32_t gi1[GC];
 #pragma unroll
   for (int k = 0; k < GC; k++) bits[k] = 0;
@@ -882,7 +891,51 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   // tests comes first (masks land in SGPR pairs), the scalar bookkeeping afterwards: a scalar instruction that
   // consumes a v_cmp result stalls the wave until the compare has left the VALU.
   auto test_tile = [&](const TileT& pj, int32_t tix) {
-    if constexpr (VBITS) {
+    if constexpr (VBITS_SCREEN) {
+      constexpr int HALF = NL_VBITS_SPLIT ? (GC + 1) / 2 : GC;
+      uint32_t uacc = 0;  // sign bit: some test of this tile is inside the band for this lane
+#pragma unroll
+      for (int k = 0; k < GC; k++) {
+        if (k == HALF) __builtin_amdgcn_sched_barrier(0);
+        const float dx = pj.x - xi[k], dy = pj.y - yi[k], dz = pj.z - zi[k];
+        const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        const uint32_t t_in = __builtin_bit_cast(uint32_t, sc->lo_in - r2), t_out = __builtin_bit_cast(uint32_t, r2 - sc->hi_out);
+        uint32_t w = t_in;  // sign clear: decided in range
+        if (!NOSELF) w |= (uint32_t)pj.gid - gi1[k];
+        bits[k] = __builtin_amdgcn_alignbit(bits[k], w, 31);  // an undecided pair goes in as "not accepted"
+        uacc |= t_in & t_out;
+      }
+      if (__builtin_amdgcn_ballot_w64((int32_t)uacc < 0) != 0) {  // (uniform, rare) the reference's expression on the original coordinates
+        const int32_t at = tix * WAVE + lane;
+        Pos<double> pe;
+        pe.x = 0, pe.y = 0, pe.z = 0;
+        if ((int32_t)uacc < 0) {
+          pe = a.sorted[sc->sidx[at]];
+          if (PBC) {
+            const int32_t wr = sc->swrap[at];
+            pe.x = add_rn(pe.x, (double)((wr & 3) - 1) * a.L[0]);
+            pe.y = add_rn(pe.y, (double)(((wr >> 2) & 3) - 1) * a.L[1]);
+            pe.z = add_rn(pe.z, (double)(((wr >> 4) & 3) - 1) * a.L[2]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < GC; k++) {
+          const float dx = pj.x - xi[k], dy = pj.y - yi[k], dz = pj.z - zi[k];
+          const float r2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          const bool unc = (int32_t)(__builtin_bit_cast(uint32_t, sc->lo_in - r2) & __builtin_bit_cast(uint32_t, r2 - sc->hi_out)) < 0;
+          if (__builtin_amdgcn_ballot_w64(unc) == 0) continue;  // uniform
+          const double xe = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pi_l.x), k), __builtin_amdgcn_readlane(__double2loint(pi_l.x), k));
+          const double ye = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pi_l.y), k), __builtin_amdgcn_readlane(__double2loint(pi_l.y), k));
+          const double ze = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pi_l.z), k), __builtin_amdgcn_readlane(__double2loint(pi_l.z), k));
+          const double ex = sub_rn(pe.x, xe), ey = sub_rn(pe.y, ye), ez = sub_rn(pe.z, ze);
+          const double e2 = add_rn(add_rn(mul_rn(ex, ex), mul_rn(ey, ey)), mul_rn(ez, ez));
+          const bool upper = NOSELF ? true : pj.gid > gi[k];
+          if (unc && !(e2 > a.rc2) && upper) bits[k] &= ~1u;  // accepted after all
+        }
+      }
+      return;
+    }
+    if constexpr (VBITS_F32) {
       // The tests go in two parts with a scheduling barrier between them: left alone the compiler hoists the
       // subtractions of all GC tests to the top of the tile, 4 live registers per test, and the kernel loses a wave per SIMD.
       constexpr int HALF = NL_VBITS_SPLIT ? (GC + 1) / 2 : GC;
@@ -1329,6 +1382,7 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
         const float rc2f = (float)a.rc2;
         const float band = 9.5367432e-7f * (ri + rj) * (ri + rj) + 2.3841858e-7f * rc2f;  // 16 2^-24 S + 4 2^-24 rc2
         sc.lo = rc2f - band, sc.hi = rc2f + band;
+        sc.lo_in = nextafterf(sc.lo, -1.0f), sc.hi_out = nextafterf(sc.hi, 3.0e38f);  // (lo > 0: rc2 dwarfs the band)
       }
       // hit masks are kept for cells whose stencil fits the mask rows the build provides per slot: one LDS batch in the
       // usual regime, up to FD_NB in a dense build (k_fill_dense); the expansion kernels re-search the rest
