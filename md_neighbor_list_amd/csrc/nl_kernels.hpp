@@ -773,9 +773,6 @@ template <typename T> struct TileOf<T, true> { typedef PosS type; };
 #ifndef NL_VBITS_SCREEN
 #define NL_VBITS_SCREEN 1
 #endif
-#ifndef NL_PKMUL
-#define NL_PKMUL 0
-#endif
 #ifndef NL_COUNT_WPE
 #define NL_COUNT_WPE 0
 #endif
@@ -789,35 +786,15 @@ template <typename T> struct TileOf<T, true> { typedef PosS type; };
 #define NL_DIAG 0
 #endif
 // r2 of one staged fp32 particle against the GC i-particles: the reference's expression, every operation rounded on
-// its own.  NL_PKMUL: the squares of two tests go through one v_pk_mul_f32 (each half is an IEEE multiply: same bits);
-// the subtractions and sums stay single instructions, which issue faster than their packed forms on gfx950.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// its own.  (The squares of two tests through one v_pk_mul_f32 -- each half an IEEE multiply, same bits -- measured
+// 10 % slower: packed fp32 issues at half the rate of the plain forms on gfx950, profiles/r02_count_sweep_investigation.txt.)
 template <int GC>
 __device__ __forceinline__ void r2_group_f32(float xj, float yj, float zj, const float* xi, const float* yi, const float* zi, float* r2) {
-#if NL_PKMUL
-#pragma unroll
-  for (int k = 0; k + 1 < GC; k += 2) {
-    const f32x2 dx = {sub_rn(xj, xi[k]), sub_rn(xj, xi[k + 1])};
-    const f32x2 dy = {sub_rn(yj, yi[k]), sub_rn(yj, yi[k + 1])};
-    const f32x2 dz = {sub_rn(zj, zi[k]), sub_rn(zj, zi[k + 1])};
-    const f32x2 sx = dx * dx, sy = dy * dy, sz = dz * dz;
-    r2[k] = add_rn(add_rn(sx.x, sy.x), sz.x);
-    r2[k + 1] = add_rn(add_rn(sx.y, sy.y), sz.y);
-  }
-  if (GC & 1) {
-    constexpr int k = GC - 1;
-    const f32x2 d = {sub_rn(xj, xi[k]), sub_rn(yj, yi[k])};
-    const float dz = sub_rn(zj, zi[k]);
-    const f32x2 sq = d * d;
-    r2[k] = add_rn(add_rn(sq.x, sq.y), mul_rn(dz, dz));
-  }
-#else
 #pragma unroll
   for (int k = 0; k < GC; k++) {
     const float dx = sub_rn(xj, xi[k]), dy = sub_rn(yj, yi[k]), dz = sub_rn(zj, zi[k]);
     r2[k] = add_rn(add_rn(mul_rn(dx, dx), mul_rn(dy, dy)), mul_rn(dz, dz));
   }
-#endif
 }
 
 // One group of GC (compile-time, 1..5) i-particles against the nj staged j-particles.
