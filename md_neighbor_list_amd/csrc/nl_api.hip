@@ -292,8 +292,14 @@ template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(
                        static_cast<const OFF*>(h->base_sorted));
     return;
   }
-  hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
-                     static_cast<const OFF*>(h->base_sorted));
+  // rows a wave loads up front: 24, or 12 where cells hold ~20 particles or fewer (a wave then has ~10 rows)
+  const bool few_rows = (double)h->n <= 21.0 * (double)std::max<int64_t>(1, h->ncell_local);
+  if (few_rows)
+    hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF, 12>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
+                       static_cast<const OFF*>(h->base_sorted));
+  else
+    hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF, 24>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
+                       static_cast<const OFF*>(h->base_sorted));
 }
 
 template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_half(nl_handle_t h, const SweepArgs<T>& a, int32_t ncells_i, hipStream_t s) {

@@ -1505,7 +1505,7 @@ __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan ov
 template <bool FULL> constexpr int EXPAND_RMAX_OF = FULL ? 192 : 160;
 constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
 
-template <typename T, bool FULL = false, bool PBC = false, typename OFF = int32_t>
+template <typename T, bool FULL = false, bool PBC = false, typename OFF = int32_t, int RB = 24>
 __global__ void __launch_bounds__(EXPAND_WAVES* WAVE, (sizeof(OFF) == 8 ? 4 : sizeof(T) == 4 ? (FULL ? 7 : 8) : 4)) __attribute__((amdgpu_num_sgpr(80)))
 k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
   constexpr int CAP = SweepCfg<T>::CAP;
@@ -1546,7 +1546,10 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
   // Rows of the cell are dealt to the waves in contiguous chunks.  A wave loads the masks and row offsets of up to
   // RB rows first and only then starts storing: vmcnt retires in order, so a load issued behind stores would wait
   // for the whole write latency of every store before it (that cost 1.7 us per row in the first version).
-  constexpr int RB = 24;
+  // RB (template parameter) is 24, or 12 in a build whose cells hold ~20 particles or fewer (the host picks the kernel by
+  // the mean): a wave with 10 rows -- BASELINE config 3 -- otherwise issues 14 x 3 loads of rows it does not have
+  // (expansion 0.201 -> 0.181 ms there; with 12 config 2 needs a second pass per wave: +13 %; both in one kernel, chosen
+  // per cell: spills under the 64-register cap, +17 %).
   const int32_t per_wave = (c.ni + EW - 1) / EW;
   const int32_t r_beg = min(wave * per_wave, c.ni), r_end = min(r_beg + per_wave, c.ni);
   uint32_t w[RB];
