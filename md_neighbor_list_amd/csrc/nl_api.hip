@@ -393,7 +393,7 @@ enum { PART_ALL = 0, PART_BEGIN = 1, PART_FINISH = 2 };
 // Mask rows for `nb` LDS batches per particle: allocated on first need (a half-shell handle that meets a minimum-image
 // or dense build; a first dense build).
 bool mask_rows_ready(nl_handle_t h, int64_t nb) {
-  const size_t need = (size_t)MASK_ROW_BYTES * (size_t)nb * ((size_t)h->n_max + 16);
+  const size_t need = (size_t)MASK_ROW_BYTES * (size_t)nb * ((size_t)h->n_max + 64);  // (+64: k_fill_masks reads whole row batches)
   if (need > h->dense_masks_limit) return false;
   if (need > h->masks_bytes || !h->masks) {
     if (dev_alloc(h, &h->masks, need) != NL_OK) {
@@ -845,7 +845,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   h->kp_alt_valid = false;
   if (h->resort_buf) (void)hipFree(h->resort_buf), h->resort_buf = nullptr;
   if ((rc = dev_alloc(h, &h->progress, 4 * (n + 16)))) return rc;
-  if ((rc = dev_alloc(h, &h->base_sorted, 8 * (n + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->base_sorted, 8 * (n + 64)))) return rc;  // (+64: k_fill_masks reads whole row batches)
   {
     const size_t nrows = (size_t)h->m[1] * h->m[2];
     // chunk per block: 4096 particles, more for very large N so that blk_base stays small
@@ -860,8 +860,8 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
     if ((rc = dev_alloc(h, &h->tmp_row, 4 * (n + 16)))) return rc;
   }
   if (h->sweep_variant >= 3 && h->sweep_variant < 5) {
-    if ((rc = dev_alloc(h, &h->masks, (size_t)MASK_ROW_BYTES * (n + 16)))) return rc;
-    h->masks_bytes = (size_t)MASK_ROW_BYTES * (n + 16);
+    if ((rc = dev_alloc(h, &h->masks, (size_t)MASK_ROW_BYTES * (n + 64)))) return rc;
+    h->masks_bytes = (size_t)MASK_ROW_BYTES * (n + 64);
   }
   if (h->sweep_variant >= 5) {
     h->rstride = (int64_t)((n + 64 + 63) / 64 * 64);

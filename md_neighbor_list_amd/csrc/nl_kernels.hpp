@@ -726,6 +726,10 @@ __device__ __forceinline__ void mask_store(uint32_t* masks, size_t slot, int lan
   reinterpret_cast<uint16_t*>(row)[lane] = (uint16_t)bits;
   reinterpret_cast<uint8_t*>(row + 2 * WAVE)[lane] = (uint8_t)(bits >> 16);
 }
+__device__ __forceinline__ void mask_store_at(char* row, int lane, uint32_t bits) {  // row: address of the 192-byte row
+  reinterpret_cast<uint16_t*>(row)[lane] = (uint16_t)bits;
+  reinterpret_cast<uint8_t*>(row + 2 * WAVE)[lane] = (uint8_t)(bits >> 16);
+}
 __device__ __forceinline__ uint32_t mask_load(const uint32_t* masks, size_t slot, int lane) {
   const char* const row = reinterpret_cast<const char*>(masks) + slot * MASK_ROW_BYTES;
   return (uint32_t)reinterpret_cast<const uint16_t*>(row)[lane] | (uint32_t)reinterpret_cast<const uint8_t*>(row + 2 * WAVE)[lane] << 16;
@@ -778,6 +782,9 @@ template <typename T> struct TileOf<T, true> { typedef PosS type; };
 #endif
 #ifndef NL_STAMP  // timing experiments only: per-phase wave cycles of the COUNT_MASKS sweep into dbg_buf[16..] (tools/count_phases.py)
 #define NL_STAMP 0
+#endif
+#ifndef NL_FILL_NOCLAMP
+#define NL_FILL_NOCLAMP 1
 #endif
 #ifndef NL_STAMP_FILL  // the same for k_fill_masks (tools/fill_phases.py); not together with NL_STAMP
 #define NL_STAMP_FILL 0
@@ -1035,12 +1042,15 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
 #endif
   if constexpr (VBITS) {
     uint32_t w[GC], tot[GC];
+    // the group's rows are mask_nb rows apart: one 64-bit row address, the others at 32-bit multiples of the stride
+    char* const row0 = reinterpret_cast<char*>(a.masks) + ((size_t)slot0 * a.mask_nb + batch) * MASK_ROW_BYTES;
+    const uint32_t row_stride = (uint32_t)a.mask_nb * MASK_ROW_BYTES;
 #pragma unroll
     for (int k = 0; k < GC; k++) {
       w[k] = __brev(~bits[k]) >> (32 - ntiles);  // tile t ended at bit ntiles - 1 - t; the bits above were never written
       if (NOSELF && lane == ((self0 + k) & (WAVE - 1))) w[k] &= ~(1u << ((self0 + k) >> 6));
       if (words_out) words_out[k] = w[k];  // (k_sweep_pipe_f32: the caller stores the words later)
-      else if (store_masks && !(NL_DIAG & 2)) mask_store(a.masks, (size_t)(slot0 + k) * a.mask_nb + batch, lane, w[k]);
+      else if (store_masks && !(NL_DIAG & 2)) mask_store_at(row0 + k * row_stride, lane, w[k]);
     }
 #pragma unroll
     for (int k = 0; k < GC; k += 2) {  // two rows per DPP sum: a row has at most CAP < 2^16 accepted partners per batch
@@ -1555,6 +1565,21 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
   uint32_t w[RB];
   OFF base[RB];
   auto load_rows = [&](int32_t r0) {
+#if NL_FILL_NOCLAMP
+    // Consecutive slots are consecutive 192-byte rows: ONE 64-bit base address per batch, the rows at immediate offsets
+    // from it.  Rows past the cell's last one are read as well (the next cells' rows, or the 64 rows of padding behind
+    // the last slot) and ignored.  (With `slot = ibeg + min(r0 + u, ni - 1)` per row the compiler spent 17 scalar
+    // instructions per row on 64-bit address arithmetic: 400 per wave.)
+    const size_t slot0 = (size_t)(c.ibeg + r0);
+    const char* const mrow0 = reinterpret_cast<const char*>(a.masks) + slot0 * MASK_ROW_BYTES;  // (one mask row per slot here)
+    const OFF* const brow0 = base_sorted + slot0;
+#pragma unroll
+    for (int u = 0; u < RB; u++) {
+      const char* const row = mrow0 + u * MASK_ROW_BYTES;
+      w[u] = (uint32_t)reinterpret_cast<const uint16_t*>(row)[lane] | (uint32_t)reinterpret_cast<const uint8_t*>(row + 2 * WAVE)[lane] << 16;
+      base[u] = brow0[u];  // (k_row_base: one gather kernel is cheaper than two dependent loads here)
+    }
+#else
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const int32_t slot = c.ibeg + min(r0 + u, c.ni - 1);
@@ -1564,10 +1589,11 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
         w[u] = (h1 >> 3) & (h1 >> 15) & (h2 >> 2) & (h2 >> 14) & 0x1FFFFu;
       }
 #else
-      w[u] = mask_load(a.masks, (size_t)slot * a.mask_nb, lane);
+      w[u] = mask_load(a.masks, (size_t)slot, lane);
 #endif
-      base[u] = base_sorted[slot];  // (k_row_base: one gather kernel is cheaper than two dependent loads here)
+      base[u] = base_sorted[slot];
     }
+#endif
   };
   load_rows(r_beg);  // issued before the id staging: independent of the segment table
   if (a.dbg & 32) return;  // diagnostics: setup + loads only
