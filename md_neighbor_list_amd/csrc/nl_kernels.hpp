@@ -1221,10 +1221,11 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
     // ---- stage: copy the stream window [win0, win0 + nj) into LDS.  The waves share the segments (slot s goes
     // to wave s mod 4: the nine never-empty slots spread 3/2/2/2); a wave copies a segment 128 particles at a
     // time with both 16-byte loads in flight before the LDS writes.
-    // (Measured twice and slower both times -- round 1 with LDS-DMA, round 2 with all of a wave's 16-byte loads forced
-    // into flight before the first LDS write, 355 against 340 us at cfg 2 and 273 against 254 at cfg 3: in the loop below
-    // the compiler waits for every load before it issues the next, 4-6 dependent round trips per wave and cell, and the
-    // kernel is the faster for it.  profiles/r02_count_staging_ab.txt)
+    // A stream of one batch (fp32, open box, COUNT_MASKS) goes by LDS-DMA instead, 16 bytes per lane (below).  History:
+    // dword LDS-DMA in round 1 and "all of a wave's 16-byte loads in flight before the first LDS write" early in round 2
+    // both measured SLOWER than this loop, in which the compiler waits for every load before it issues the next
+    // (profiles/r02_count_staging_ab.txt) -- the staging phase was starved of issue slots, not waiting for memory
+    // (DESIGN.md section 5); with s_setprio around the tile loop and 16-byte DMA it is 2 300 cycles of a wave's 36 000.
     float rmax = 0.f;  // SCREEN: largest L1 norm of the relative coordinates this thread stages
     constexpr bool DMA = NL_STAGE_DMA && sizeof(T) == 4 && !PBC && !SCREEN && MODE == MODE_COUNT_MASKS;
     for (int32_t sg = wave; sg < NSEG; sg += NW) {
