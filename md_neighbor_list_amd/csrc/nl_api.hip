@@ -28,6 +28,7 @@ struct HostResult {
 constexpr int META_TOTAL = 18;  // int32 offset of total_lo from the status word
 constexpr int META_FULL27 = 1;  // number of cells the half-shell path hands to the 27-cell search (first "ticket" word)
 constexpr int META_PIPE = 2;    // 8 chunk-ticket counters of the pipelined COUNT sweep, one per XCD ("ticket" words 2..9)
+constexpr int META_FILL_LIST = 10;  // number of cells k_fill_masks hands to k_fill_list ("ticket" word 10)
 constexpr int META_WORDS = 20;
 
 }  // namespace
@@ -272,6 +273,7 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.full27_list = h->full27_list;
   a.full27_count = reinterpret_cast<int32_t*>(h->status) + META_FULL27;
   a.pipe_ticket = reinterpret_cast<int32_t*>(h->status) + META_PIPE;
+  a.fill_list_count = reinterpret_cast<int32_t*>(h->status) + META_FILL_LIST;
   a.pbc = h->pbc ? 1 : 0;
   for (int d = 0; d < 3; d++) a.ms[d] = (T)(h->L[d] / h->m[d]);
   for (int d = 0; d < 3; d++) a.L[d] = (T)h->L[d];
@@ -300,6 +302,8 @@ template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(
   else
     hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF, 24>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
                        static_cast<const OFF*>(h->base_sorted));
+  // cells without masks (a stream of several LDS batches among one-batch neighbours): a second distance search
+  hipLaunchKernelGGL((k_fill_list<T, FULL, PBC>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, a);
 }
 
 template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_half(nl_handle_t h, const SweepArgs<T>& a, int32_t ncells_i, hipStream_t s) {

@@ -708,6 +708,7 @@ template <typename T> struct SweepArgs {
   int32_t mask_nb;                         // mask rows per sorted slot: 1, or up to FD_NB LDS batches in a dense build
   int32_t* __restrict__ full27_list;       // local cell indices of the cells k_full27 builds (irregular stencil)
   int32_t* __restrict__ full27_count;      // their number: a meta word next to the status word, zeroed with it
+  int32_t* __restrict__ fill_list_count;   // cells k_fill_masks hands to k_fill_list (in full27_list; a meta word of its own)
   int32_t* __restrict__ pipe_ticket;       // [8] k_sweep_pipe_f32: chunk tickets, one counter per XCD (meta words, zeroed per build)
   uint32_t* __restrict__ masks;  // [n] rows of 64 x 24 bits (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
@@ -1547,10 +1548,10 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
   }
   if (!ok) return;
   if (c.total_j > CAP) {
-    // No masks for this cell (its stencil needed several LDS batches in COUNT_MASKS): search it again, as
-    // k_sweep<FILL> does, in small batches through the id buffer.  Rare (very dense cells only).
-    constexpr int CAPS = (int)(CAP * sizeof(int32_t) / (sizeof(Pos<T>))) / WAVE * WAVE;
-    cell_search<T, MODE_FILL, CAPS, EW, FULL, PBC>(a, c, reinterpret_cast<Pos<T>*>(gids), tid, lane, wave);
+    // No masks for this cell (its stencil needed several LDS batches in COUNT_MASKS): it goes on the list of
+    // k_fill_list, which searches it again as k_sweep<FILL> does.  Rare (very dense cells only).
+    // (k_fill_list, a kernel of its own: inlined here the re-search cost this kernel 74 spilled SGPRs and 6 % of its time)
+    if (tid == 0) a.full27_list[atomicAdd(a.fill_list_count, 1)] = c.cx + (c.cy + c.cz * a.my) * a.mx;  // local cell index
     return;
   }
 
@@ -1717,6 +1718,27 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
     atomicAdd(slot + 9, 1ull);
   }
 #endif
+}
+
+// The cells k_fill_masks found without masks (local cell indices in full27_list): the rows by a second distance search,
+// the batched FILL search of k_sweep<FILL>, a workgroup per listed cell.
+template <typename T, bool FULL = false, bool PBC = false>
+__global__ void __launch_bounds__(SWEEP_WAVES* WAVE) k_fill_list(SweepArgs<T> a) {
+  constexpr int CAP = sweep_cap<T, MODE_FILL>();
+  constexpr bool SCREEN = sizeof(T) == 8;
+  __shared__ __attribute__((aligned(32))) char tile_bytes[SCREEN ? screen_lds_bytes(CAP) : CAP * (int)sizeof(Pos<T>)];
+  Pos<T>* const tile = reinterpret_cast<Pos<T>*>(tile_bytes);
+  if (a.total[0] > a.capacity) return;  // (k_fill_masks has raised ST_CAPACITY)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int32_t count = *a.fill_list_count;
+  for (int32_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    if (idx != (int32_t)blockIdx.x) __syncthreads();  // everyone is done with the previous cell's LDS
+    const int32_t cell = a.full27_list[idx];
+    const int32_t row = cell / a.mx, cx = cell - row * a.mx, cz = row / a.my, cy = row - cz * a.my;
+    CellCtx c;
+    if (!cell_setup_at(a, lane, cx, cy, cz, c)) continue;
+    cell_search<T, MODE_FILL, CAP, SWEEP_WAVES, FULL, PBC, SCREEN>(a, c, tile, tid, lane, wave);
+  }
 }
 
 // ------------------------------------------------------------------------------------- list from masks, dense cells
