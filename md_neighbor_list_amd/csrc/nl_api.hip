@@ -83,7 +83,8 @@ struct nl_handle_s {
   size_t masks_bytes = 0;          // size of the masks allocation
   int32_t b_isplit = 1;            // this build, two-sweep path: workgroups per cell
   int isplit_env = 0;              // NL_ISPLIT: 0 = by density
-  int pipe_wg_per_cu = 0;          // NL_PIPE: workgroups per CU of the pipelined COUNT sweep (k_sweep_pipe_f32); 0 = one workgroup per cell
+  int pipe_wg_per_cu = 1;          // NL_PIPE: 1 (default) = a workgroup per cell, single-batch cells only (k_sweep_lean_f32 + list);
+                                   // 0 = k_sweep_count_masks_f32; 4 = pipelined persistent sweep, workgroups per CU; >= 8 = single-buffer persistent sweep
   bool dense_masks_off = false;    // NL_DENSE_MASKS=0: dense builds use two distance sweeps (the round-1 path)
   size_t dense_masks_limit = (size_t)64 << 30;  // most memory the mask rows of a dense build may take
   int half_cpb = 4;                // cells a workgroup of k_sweep_half walks (NL_HALF_CPB)
@@ -348,7 +349,9 @@ template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h,
           SweepArgs<T> ap = a;
           ap.ncells_grid = ncells_i;
           const int32_t grid = std::max(1, std::min(ncells_i, h->pipe_wg_per_cu * h->num_cus));
-          if (h->pipe_wg_per_cu >= 8)  // NL_PIPE >= 8: single-buffer persistent workgroups of 4 waves
+          if (h->pipe_wg_per_cu == 1)  // NL_PIPE = 1: a workgroup per cell, single-batch cells only
+            hipLaunchKernelGGL((k_sweep_lean_f32<FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, ap);
+          else if (h->pipe_wg_per_cu >= 8)  // NL_PIPE >= 8: single-buffer persistent workgroups of 4 waves
             hipLaunchKernelGGL((k_sweep_persist_f32<FULL>), dim3(grid), dim3(PERSIST_WAVES * WAVE), 0, s, ap);
           else
             hipLaunchKernelGGL((k_sweep_pipe_f32<FULL>), dim3(grid), dim3(PIPE_WAVES * WAVE), 0, s, ap);

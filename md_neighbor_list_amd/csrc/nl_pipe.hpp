@@ -363,6 +363,31 @@ k_sweep_persist_f32(SweepArgs<float> a) {
   pipe_flush(a, pend, lane);
 }
 
+// One workgroup per cell, like k_sweep_count_masks_f32, but only what a single-batch cell needs: the stream by LDS-DMA,
+// the groups' i-particles taken from the staged stream (no loads of their own), no batch loop, no progress words; a
+// cell whose stream does not fit goes on the list of k_sweep_list_f32.  (NL_PIPE=1.)
+template <bool FULL>
+__global__ void __launch_bounds__(SWEEP_WAVES* WAVE, 8) __attribute__((amdgpu_num_sgpr(80))) k_sweep_lean_f32(SweepArgs<float> a) {
+  constexpr int CAP = SweepCfg<float>::CAP, NW = SWEEP_WAVES;
+  __shared__ __attribute__((aligned(32))) Pos<float> buf[CAP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if NL_PRIO
+  __builtin_amdgcn_s_setprio(NL_PRIO);  // everything but the tile loop of search_group
+#endif
+  CellCtx c;
+  if (!cell_setup(a, lane, c)) return;
+  if (c.total_j > CAP) {  // (rare) several LDS batches: k_sweep_list_f32
+    if (tid == 0) a.full27_list[atomicAdd(a.full27_count, 1)] = c.cx + (c.cy + c.cz * a.my) * a.mx;
+    return;
+  }
+  pipe_stage<NW>(a, c, buf, tid, lane, wave);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  PipePending pend;
+  pend.gcount = 0, pend.mine = 0, pend.row_l = 0, pend.slot0 = 0;
+  pipe_search<FULL, NW>(a, c, buf, lane, wave, pend);
+  pipe_flush(a, pend, lane);
+}
+
 // The cells k_sweep_pipe_f32 left out (local cell indices in full27_list): the batched search, a workgroup per cell.
 template <bool FULL>
 __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80))) k_sweep_list_f32(SweepArgs<float> a) {

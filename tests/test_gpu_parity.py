@@ -960,11 +960,11 @@ def test_resort_then_rebuild_equals_the_oracle_on_the_permuted_input(dtype):
         # a second round re-sorts an already sorted system: the order is the identity up to ties inside a cell
 
 
-@pytest.mark.parametrize("pipe", [4, 8])
+@pytest.mark.parametrize("pipe", [0, 4, 8])
 def test_persistent_count_sweeps(pipe, monkeypatch):
-    """NL_PIPE (opt-in): the COUNT_MASKS sweep by persistent workgroups that walk chunks of cells -- 4: 8 waves, the next
-    cell's stream arriving by LDS-DMA during the search (k_sweep_pipe_f32); 8: 4 waves, one buffer
-    (k_sweep_persist_f32).  Same lists as the default kernels: half and full list, a box whose cluster puts cells on the
+    """NL_PIPE: the other forms of the fp32 COUNT_MASKS sweep (default 1: k_sweep_lean_f32) -- 0: k_sweep_count_masks_f32, batch
+    loop inlined; 4: persistent workgroups of 8 waves that walk chunks of cells, the next cell's stream arriving by LDS-DMA
+    during the search (k_sweep_pipe_f32); 8: 4 waves, one buffer (k_sweep_persist_f32).  Same lists: half and full list, a box whose cluster puts cells on the
     hand-over list of the batched search (k_sweep_list_f32), boxes with fewer chunks than workgroups."""
     import torch
 

@@ -57,7 +57,7 @@ def test_slab_union_equals_global_list_gpu(world, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipe", [4, 8])
+@pytest.mark.parametrize("pipe", [0, 4, 8])
 def test_slab_builds_with_the_persistent_count_sweeps(pipe, monkeypatch):
     """NL_PIPE (opt-in persistent COUNT kernels, nl_pipe.hpp) in slab builds: the owned layers start at local layer 1."""
     monkeypatch.setenv("NL_PIPE", str(pipe))  # (the spawned ranks inherit the environment)

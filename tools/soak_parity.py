@@ -22,7 +22,7 @@ for case in range(cases):
     os.environ["NL_SWEEP_VARIANT"] = os.environ.get("SOAK_VARIANT") or str(rng.choice([1, 3, 3, 5, 6]))
     os.environ["NL_OFFSET_WIDTH"] = str(rng.choice([0, 0, 64]))
     os.environ["NL_BINNING"] = str(rng.integers(0, 2))
-    os.environ["NL_PIPE"] = str(rng.choice([0, 0, 0, 4, 8]))  # persistent COUNT sweeps (fp32 open-box mask builds only)
+    os.environ["NL_PIPE"] = str(rng.choice([1, 1, 0, 4, 8]))  # persistent COUNT sweeps (fp32 open-box mask builds only)
     rc = float(rng.uniform(0.5, 5.0))
     mesh = rng.integers(3, 14, size=3)
     box = tuple(float(m * rc * rng.uniform(1.0, 1.3)) for m in mesh)
