@@ -1,4 +1,5 @@
-// nl_pipe.hpp -- the COUNT_MASKS sweep as a software pipeline over cells (fp32, open box).
+// nl_pipe.hpp -- the fp32 open-box COUNT_MASKS sweep for cells whose stream fits one LDS buffer: k_sweep_lean_f32 (the
+// default: a workgroup per cell) at the end of this file, and first its two persistent forms, a software pipeline over cells.
 //
 // k_sweep_count_masks_f32 gives every cell its own workgroup, and a wave of it spends more than half of its life
 // outside the pair search: kernel arguments, the cell's segment table (two dependent loads), the stencil stream
