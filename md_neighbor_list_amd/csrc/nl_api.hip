@@ -26,8 +26,7 @@ struct HostResult {
   int64_t total() const { return (int64_t)(((uint64_t)total_hi << 32) | total_lo); }
 };
 constexpr int META_TOTAL = 18;  // int32 offset of total_lo from the status word
-constexpr int META_FULL27 = 1;  // number of cells the half-shell path hands to the 27-cell search (first "ticket" word)
-constexpr int META_PIPE = 2;    // 8 chunk-ticket counters of the pipelined COUNT sweep, one per XCD ("ticket" words 2..9)
+constexpr int META_FULL27 = 1;  // number of cells the COUNT sweep hands to the batched search (first "ticket" word)
 constexpr int META_FILL_LIST = 10;  // number of cells k_fill_masks hands to k_fill_list ("ticket" word 10)
 constexpr int META_WORDS = 20;
 
@@ -70,24 +69,14 @@ struct nl_handle_s {
   bool bin_two_level = true;      // NL_BINNING=1 selects the atomic-rank path (k_hash/k_reorder)
   void* base_sorted = nullptr;     // key_pointer of every sorted slot (mask expansion), same width as key_pointer
   uint32_t* masks = nullptr;       // [n][64] hit bits of every sorted slot, between COUNT_MASKS and k_fill_masks
-  // half-shell search (nl_half.hpp): F words, R words, their counts
-  uint16_t* fmask = nullptr;
-  unsigned long long* rmask = nullptr;
-  uint32_t* fcnt = nullptr;
-  uint8_t* rcnt = nullptr;
   int32_t* full27_list = nullptr;
   void* resort_buf = nullptr;      // scratch of nl_resort (32 bytes per particle), allocated on first use
-  int64_t rstride = 0;
-  bool b_half = false;             // this build: half-shell search
   int32_t b_mask_nb = 1;           // this build: mask rows per sorted slot (> 1: dense build, k_fill_dense)
   size_t masks_bytes = 0;          // size of the masks allocation
   int32_t b_isplit = 1;            // this build, two-sweep path: workgroups per cell
   int isplit_env = 0;              // NL_ISPLIT: 0 = by density
-  int pipe_wg_per_cu = 1;          // NL_PIPE: 1 (default) = a workgroup per cell, single-batch cells only (k_sweep_lean_f32 + list);
-                                   // 0 = k_sweep_count_masks_f32; 4 = pipelined persistent sweep, workgroups per CU; >= 8 = single-buffer persistent sweep
   bool dense_masks_off = false;    // NL_DENSE_MASKS=0: dense builds use two distance sweeps (the round-1 path)
   size_t dense_masks_limit = (size_t)64 << 30;  // most memory the mask rows of a dense build may take
-  int half_cpb = 4;                // cells a workgroup of k_sweep_half walks (NL_HALF_CPB)
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps;
                                    // 3 (default): COUNT keeping hit masks + mask expansion
                                    // (2 = persistent LDS-DMA sweeps, 4 / 5 = matrix-core searches: measured slower or a draw
@@ -268,12 +257,10 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.capacity = h->capacity;
   a.status = h->status;
   a.masks = h->masks;
-  a.fmask = h->fmask, a.rmask = h->rmask, a.fcnt = h->fcnt, a.rcnt = h->rcnt, a.rstride = h->rstride;
-  a.isplit = 1, a.cells_per_block = 1, a.ncells_grid = 0;
+  a.isplit = 1;
   a.mask_nb = h->b_mask_nb;
   a.full27_list = h->full27_list;
   a.full27_count = reinterpret_cast<int32_t*>(h->status) + META_FULL27;
-  a.pipe_ticket = reinterpret_cast<int32_t*>(h->status) + META_PIPE;
   a.fill_list_count = reinterpret_cast<int32_t*>(h->status) + META_FILL_LIST;
   a.pbc = h->pbc ? 1 : 0;
   for (int d = 0; d < 3; d++) a.ms[d] = (T)(h->L[d] / h->m[d]);
@@ -307,55 +294,17 @@ template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(
   hipLaunchKernelGGL((k_fill_list<T, FULL, PBC>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, a);
 }
 
-template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_half(nl_handle_t h, const SweepArgs<T>& a, int32_t ncells_i, hipStream_t s) {
-  const int32_t nbp = (h->n + 255) / 256;
-  if (h->n > 0)
-    hipLaunchKernelGGL(k_row_base<OFF>, dim3(nbp), dim3(256), 0, s, static_cast<const OFF*>(h->key_pointer), h->sorted_row,
-                       h->n_rows, h->n, static_cast<OFF*>(h->base_sorted));
-  SweepArgs<T> ah = a;
-  ah.cells_per_block = h->half_cpb, ah.ncells_grid = ncells_i;
-  hipLaunchKernelGGL((k_fill_half<T, FULL, false, OFF>), dim3((ncells_i + h->half_cpb - 1) / h->half_cpb), dim3(HF_WAVES * WAVE), 0, s, ah,
-                     static_cast<const OFF*>(h->base_sorted));
-  hipLaunchKernelGGL((k_full27<T, MODE_FILL, FULL, false>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
-}
-
 template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h, int mode, hipStream_t s) {
   const int32_t owned_layers = h->b_slab ? h->b_mzl - 2 : h->b_mzl;
   const int32_t ncells_i = h->m[0] * h->m[1] * owned_layers;
   const SweepArgs<T> a = sweep_args<T>(h);
-  if (h->b_half && mode == MODE_COUNT) {
-    // every local layer but a slab's upper ghost layer sweeps (the lower ghost layer is the lower neighbour of layer 1)
-    const int32_t ncells_h = h->m[0] * h->m[1] * (h->b_slab ? h->b_mzl - 1 : h->b_mzl);
-    SweepArgs<T> ah = a;
-    ah.cells_per_block = h->half_cpb, ah.ncells_grid = ncells_h;
-    hipLaunchKernelGGL((k_sweep_half<T, FULL, false>), dim3((ncells_h + h->half_cpb - 1) / h->half_cpb), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
-    ah.ncells_grid = ncells_i;  // cells with an irregular stencil: counted by the 27-cell search
-    hipLaunchKernelGGL((k_full27<T, MODE_COUNT, FULL, false>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ah);
-    if (h->n > 0)
-      hipLaunchKernelGGL(k_half_counts, dim3((h->n + 255) / 256), dim3(256), 0, s, h->fcnt, h->rcnt, h->rstride, h->sorted_row,
-                         h->n_rows, h->n, h->count);
-    return;
-  }
-  if (h->b_half && h->b_variant >= 6) {  // (variant 5: half-shell COUNT, rows by a second 27-cell sweep -- diagnostics)
-    if (h->b_wide) launch_fill_half<T, FULL, PBC, int64_t>(h, a, ncells_i, s);
-    else launch_fill_half<T, FULL, PBC, int32_t>(h, a, ncells_i, s);
-    return;
-  }
   if (h->b_use_masks) {
     if (mode == MODE_COUNT) {
       if constexpr (sizeof(T) == 4) {
-        if (!PBC && h->b_mask_nb == 1 && h->pipe_wg_per_cu > 0) {
-          // persistent workgroups, each a software pipeline over a run of consecutive cells (nl_pipe.hpp)
-          SweepArgs<T> ap = a;
-          ap.ncells_grid = ncells_i;
-          const int32_t grid = std::max(1, std::min(ncells_i, h->pipe_wg_per_cu * h->num_cus));
-          if (h->pipe_wg_per_cu == 1)  // NL_PIPE = 1: a workgroup per cell, single-batch cells only
-            hipLaunchKernelGGL((k_sweep_lean_f32<FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, ap);
-          else if (h->pipe_wg_per_cu >= 8)  // NL_PIPE >= 8: single-buffer persistent workgroups of 4 waves
-            hipLaunchKernelGGL((k_sweep_persist_f32<FULL>), dim3(grid), dim3(PERSIST_WAVES * WAVE), 0, s, ap);
-          else
-            hipLaunchKernelGGL((k_sweep_pipe_f32<FULL>), dim3(grid), dim3(PIPE_WAVES * WAVE), 0, s, ap);
-          hipLaunchKernelGGL((k_sweep_list_f32<FULL>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, ap);
+        if (!PBC && h->b_mask_nb == 1) {
+          // a workgroup per cell, single-batch cells only; the others go on the hand-over list of the batched search
+          hipLaunchKernelGGL((k_sweep_lean_f32<FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+          hipLaunchKernelGGL((k_sweep_list_f32<FULL>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, a);
         } else {
           hipLaunchKernelGGL((k_sweep_count_masks_f32<FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), h->dbg_lds_pad, s, a);
         }
@@ -427,12 +376,7 @@ void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int
   // beyond the batch size most cells would fall back to a re-search in small batches, so use two full sweeps there.
   const double mean_stream = ncl > 0 ? 27.0 * n / (double)ncl : 0.0;
   const bool sparse_enough = mean_stream <= 0.85 * SweepCfg<T>::CAP;  // mean stencil <= 1088: <= 40.3 per cell
-  // (open box only: in minimum-image mode a pair is decided in the frame of the row that stores it -- (q_j + L) - q_i
-  // and (q_i - L) - q_j round differently -- and the half-shell search tests a pair once, in the frame of the lower
-  // cell's particle, whichever row stores it: a seeded soak found the one-ulp case.  Such builds take variant 3.)
-  h->b_half = h->b_variant >= 5 && h->fmask && sparse_enough && !h->pbc;
-  if (h->b_variant >= 5 && !h->b_half) h->b_variant = 3;
-  h->b_use_masks = h->b_variant >= 3 && h->b_variant < 5 && sparse_enough && mask_rows_ready(h, 1);
+  h->b_use_masks = h->b_variant >= 3 && sparse_enough && mask_rows_ready(h, 1);
   h->b_mask_nb = 1;
   if (h->b_variant >= 3 && !sparse_enough && !h->dense_masks_off) {
     // Dense cells: hit masks for up to FD_NB LDS batches per slot instead of a second distance sweep, when the streams
@@ -445,7 +389,7 @@ void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int
   {  // NL_ISPLIT (diagnostics): workgroups per cell in the two-sweep path; default 1 (see sweep_cell)
     int32_t sp = std::max(1, std::min(h->isplit_env, 32));
     if ((int64_t)sp * ncl > 2000000000LL) sp = 1;
-    h->b_isplit = (h->b_use_masks || h->b_half) ? 1 : sp;
+    h->b_isplit = h->b_use_masks ? 1 : sp;
   }
   h->b_wide = h->offset_width == 64 || (h->offset_width == 0 && h->capacity > 2147483647LL);
   h->kp_alt_valid = false;
@@ -797,11 +741,9 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
-    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : atoi(v) >= 6 ? 6 : atoi(v) == 5 ? 5 : 3;
+    if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : 3;
     if (const char* v = getenv("NL_ISPLIT")) h->isplit_env = std::max(0, atoi(v));
-    if (const char* v = getenv("NL_PIPE")) h->pipe_wg_per_cu = std::max(0, std::min(atoi(v), 64));
     if (const char* v = getenv("NL_DENSE_MASKS")) h->dense_masks_off = atoi(v) == 0;
-    if (const char* v = getenv("NL_HALF_CPB")) h->half_cpb = std::max(1, atoi(v));
     if (const char* v = getenv("NL_OFFSET_WIDTH")) h->offset_width = atoi(v) == 64 ? 64 : atoi(v) == 32 ? 32 : 0;
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_GRAPH")) h->use_graph = atoi(v) != 0;
@@ -817,7 +759,7 @@ int nl_destroy(nl_handle_t h) {
   if (!h) return NL_ERR_ARG;
   (void)hipSetDevice(h->device);
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
-  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->kp_alt, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->fmask, h->rmask, h->fcnt, h->rcnt, h->full27_list, h->resort_buf, h->dbg_buf, h->cell_count,
+  void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->kp_alt, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->full27_list, h->resort_buf, h->dbg_buf, h->cell_count,
                   h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -867,16 +809,9 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
     if ((rc = dev_alloc(h, &h->tmp_pos, pos_bytes * (n + 16)))) return rc;
     if ((rc = dev_alloc(h, &h->tmp_row, 4 * (n + 16)))) return rc;
   }
-  if (h->sweep_variant >= 3 && h->sweep_variant < 5) {
+  if (h->sweep_variant >= 3) {
     if ((rc = dev_alloc(h, &h->masks, (size_t)MASK_ROW_BYTES * (n + 64)))) return rc;
     h->masks_bytes = (size_t)MASK_ROW_BYTES * (n + 64);
-  }
-  if (h->sweep_variant >= 5) {
-    h->rstride = (int64_t)((n + 64 + 63) / 64 * 64);
-    if ((rc = dev_alloc(h, &h->fmask, 2 * (size_t)WAVE * (n + 16)))) return rc;
-    if ((rc = dev_alloc(h, &h->rmask, 8 * (size_t)HS_NUP * (size_t)h->rstride))) return rc;
-    if ((rc = dev_alloc(h, &h->fcnt, 4 * (n + 16)))) return rc;
-    if ((rc = dev_alloc(h, &h->rcnt, (size_t)HS_NUP * (size_t)h->rstride))) return rc;
   }
   // cells handed from one search kernel to another: half-shell -> 27-cell search, pipelined COUNT -> batched search
   if ((rc = dev_alloc(h, &h->full27_list, 4 * ((size_t)h->ncell + 16)))) return rc;
@@ -1231,7 +1166,7 @@ int nl_get_build_info(nl_handle_t h, int32_t info[8]) {
   for (int k = 4; k < 8; k++) info[k] = 0;
   info[4] = h->b_wide ? 64 : 32;
   info[5] = h->b_mask_nb;
-  info[6] = h->b_half ? 1 : 0;
+  info[6] = 0;
   info[0] = h->b_use_masks ? 1 : 0;
   info[1] = h->sweep_variant;
   info[2] = h->dtype == NL_F32 ? SweepCfg<float>::CAP : SweepCfg<double>::CAP;

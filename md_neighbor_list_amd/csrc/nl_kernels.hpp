@@ -697,19 +697,11 @@ template <typename T> struct SweepArgs {
                                   // at their image, coordinate -+ L (nl_set_periodic; not in the reference)
   T ms[3];                        // cell edge (screened fp64 search: origin of the relative coordinates)
   int32_t z_origin;               // global z layer of local layer 0
-  // half-shell search (nl_half.hpp)
-  uint16_t* __restrict__ fmask;            // [n][64] F words: bit t of lane l of a slot = staged particle t*64 + l accepted
-  unsigned long long* __restrict__ rmask;  // [13][rstride] R words: bit b of (k, slot) = particle b of lower cell k accepted
-  uint32_t* __restrict__ fcnt;             // [n] forward count of a slot (HS_FINAL: counted by the 27-cell search)
-  uint8_t* __restrict__ rcnt;              // [13][rstride] popcount of the R words
-  int64_t rstride;
-  int32_t cells_per_block, ncells_grid;    // k_sweep_half / k_fill_half: cells a workgroup walks, cells of the launch
   int32_t isplit;                          // two-sweep path: workgroups per cell (each a part of the cell's i-particles)
   int32_t mask_nb;                         // mask rows per sorted slot: 1, or up to FD_NB LDS batches in a dense build
-  int32_t* __restrict__ full27_list;       // local cell indices of the cells k_full27 builds (irregular stencil)
-  int32_t* __restrict__ full27_count;      // their number: a meta word next to the status word, zeroed with it
-  int32_t* __restrict__ fill_list_count;   // cells k_fill_masks hands to k_fill_list (in full27_list; a meta word of its own)
-  int32_t* __restrict__ pipe_ticket;       // [8] k_sweep_pipe_f32: chunk tickets, one counter per XCD (meta words, zeroed per build)
+  int32_t* __restrict__ full27_list;       // hand-over list: local cell indices of the cells a kernel leaves to the batched search
+  int32_t* __restrict__ full27_count;      // their number (COUNT pass): a meta word next to the status word, zeroed with it
+  int32_t* __restrict__ fill_list_count;   // cells the expansion hands to k_fill_list (in full27_list; a meta word of its own)
   uint32_t* __restrict__ masks;  // [n] rows of 64 x 24 bits (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
   int32_t dbg;  // diagnostics only (NL_DEBUG_FLAGS): 1 = skip the search, 2 = skip the staging copy; 0 in production
@@ -1050,7 +1042,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
     for (int k = 0; k < GC; k++) {
       w[k] = __brev(~bits[k]) >> (32 - ntiles);  // tile t ended at bit ntiles - 1 - t; the bits above were never written
       if (NOSELF && lane == ((self0 + k) & (WAVE - 1))) w[k] &= ~(1u << ((self0 + k) >> 6));
-      if (words_out) words_out[k] = w[k];  // (k_sweep_pipe_f32: the caller stores the words later)
+      if (words_out) words_out[k] = w[k];  // (k_sweep_lean_f32: the caller stores the words after the search)
       else if (store_masks && !(NL_DIAG & 2)) mask_store_at(row0 + k * row_stride, lane, w[k]);
     }
 #pragma unroll
@@ -1867,8 +1859,7 @@ __global__ void __launch_bounds__(FD_WAVES* WAVE) k_fill_dense(SweepArgs<T> a, c
 
 }  // namespace nl
 
-#include "nl_half.hpp"
-#include "nl_pipe.hpp"
+#include "nl_lean.hpp"
 
 namespace nl {
 

@@ -15,7 +15,7 @@ from tests.util import GOLDEN, canonical_csr, golden_names, gpu_build, load_gold
 
 pytestmark = pytest.mark.gpu
 
-SWEEP_VARIANTS = [1, 3, 5, 6]  # NL_SWEEP_VARIANT values the library accepts; 5 = half-shell COUNT + 27-cell FILL, 6 = half-shell search + expansion
+SWEEP_VARIANTS = [1, 3]  # NL_SWEEP_VARIANT values the library accepts: 1 = COUNT + FILL distance sweeps, 3 = hit masks + expansion
 
 
 def _po():
@@ -408,7 +408,7 @@ def test_random_mask_pipeline_boxes_against_oracle(variant, monkeypatch):
         ref = _po().build(q, rc, box)
         nl, nop, kp, sl = gpu_build(q, rc, box)
         info = nl.build_info()
-        assert (info["masks"] or variant >= 5) and info["variant"] == variant, (case, info)
+        assert info["masks"] and info["variant"] == variant, (case, info)
         assert int(kp[-1]) == ref.npairs, case
         assert np.array_equal(nop, ref.number_of_partners), case
         assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), case
@@ -960,18 +960,15 @@ def test_resort_then_rebuild_equals_the_oracle_on_the_permuted_input(dtype):
         # a second round re-sorts an already sorted system: the order is the identity up to ties inside a cell
 
 
-@pytest.mark.parametrize("pipe", [0, 4, 8])
-def test_persistent_count_sweeps(pipe, monkeypatch):
-    """NL_PIPE: the other forms of the fp32 COUNT_MASKS sweep (default 1: k_sweep_lean_f32) -- 0: k_sweep_count_masks_f32, batch
-    loop inlined; 4: persistent workgroups of 8 waves that walk chunks of cells, the next cell's stream arriving by LDS-DMA
-    during the search (k_sweep_pipe_f32); 8: 4 waves, one buffer (k_sweep_persist_f32).  Same lists: half and full list, a box whose cluster puts cells on the
-    hand-over list of the batched search (k_sweep_list_f32), boxes with fewer chunks than workgroups."""
+def test_cells_handed_to_the_batched_search():
+    """Cells whose stencil stream does not fit one LDS batch are put on a device-side list by the COUNT sweep and searched
+    by the batched kernels (k_sweep_list_f32 / k_fill_list): a box whose cluster produces such cells among one-batch
+    neighbours, half and full list, next to plain boxes."""
     import torch
 
     from md_neighbor_list_amd import NeighListGPU
 
-    monkeypatch.setenv("NL_PIPE", str(pipe))
-    rng = np.random.default_rng(5 + pipe)
+    rng = np.random.default_rng(5)
     cases = [(50000, (36.84, 36.84, 36.84), 3.3, 0.0), (9000, (25.0, 14.0, 19.0), 3.1, 0.0), (4096, (16.0, 16.0, 16.0), 3.3, 0.0),
              (60000, (40.0, 40.0, 40.0), 3.3, 0.12), (120000, (50.0, 60.0, 45.0), 3.0, 0.02)]
     for n, box, rc, clustered in cases:

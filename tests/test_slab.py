@@ -57,15 +57,6 @@ def test_slab_union_equals_global_list_gpu(world, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipe", [0, 4, 8])
-def test_slab_builds_with_the_persistent_count_sweeps(pipe, monkeypatch):
-    """NL_PIPE (opt-in persistent COUNT kernels, nl_pipe.hpp) in slab builds: the owned layers start at local layer 1."""
-    monkeypatch.setenv("NL_PIPE", str(pipe))  # (the spawned ranks inherit the environment)
-    res = run(2, "hip", (60000, (30.0, 30.0, 66.0), 3.3, "float32", 86))
-    assert res[0] == "ok"
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("world,case", [
     (2, (60000, (30.0, 30.0, 66.0), 3.3, "float32", 83)),
     (3, (50000, (25.0, 25.0, 80.0), 3.3, "float64", 84)),
