@@ -75,6 +75,10 @@ struct nl_handle_s {
   size_t masks_bytes = 0;          // size of the masks allocation
   int32_t b_isplit = 1;            // this build, two-sweep path: workgroups per cell
   int isplit_env = 0;              // NL_ISPLIT: 0 = by density
+  int rows_env = 0;                // NL_ROWS: 0 (default) = the 27-cell path, -1 = the fine-row search where a build qualifies,
+                                   // 1..3 = force RowsCfg<V - 1> where it qualifies (tests)
+  bool b_rows = false;             // this build: fine rows (k_bin_cells<FINE>, k_sweep_rows_f32, k_fill_rows); the cell table is
+  int b_rows_v = 0;                // fine_start (4 M + 1 entries); RowsCfg of the build
   bool dense_masks_off = false;    // NL_DENSE_MASKS=0: dense builds use two distance sweeps (the round-1 path)
   size_t dense_masks_limit = (size_t)64 << 30;  // most memory the mask rows of a dense build may take
   int sweep_variant = 3;           // 1: COUNT + FILL distance sweeps;
@@ -271,6 +275,53 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   return a;
 }
 
+RowsArgs rows_args(nl_handle_t h) {
+  RowsArgs a;
+  a.sorted = static_cast<const Pos<float>*>(h->sorted);
+  a.sorted_row = h->sorted_row, a.sorted_gid = h->sorted_gid;
+  a.fine_start = h->cell_start;
+  a.mx = h->m[0], a.my = h->m[1], a.mzl = h->b_mzl, a.slab = h->b_slab;
+  a.div_mx = fastdiv_make((uint32_t)h->m[0]), a.div_my = fastdiv_make((uint32_t)h->m[1]);
+  a.rc2 = h->rc2_f;
+  a.count = h->count;
+  a.masks = h->masks;
+  a.key_pointer = h->key_pointer;
+  a.list = h->list;
+  a.total = h->totals + 1;
+  a.capacity = h->capacity;
+  a.status = h->status;
+  a.over_list = h->full27_list;
+  a.over_count = reinterpret_cast<int32_t*>(h->status) + META_FULL27;
+  a.wide = h->b_wide ? 1 : 0;
+  a.dbg_buf = h->dbg_buf;
+  return a;
+}
+
+// The fine-row path (nl_rows.hpp).  V: RowsCfg of the build.
+template <int V, bool FULL> void launch_rows(nl_handle_t h, int mode, int32_t ncells_i, hipStream_t s) {
+  const RowsArgs a = rows_args(h);
+  const int32_t over_grid = 2 * h->num_cus;
+  if (mode == MODE_COUNT) {
+    hipLaunchKernelGGL((k_sweep_rows_f32<V, FULL>), dim3(ncells_i), dim3(ROWS_WAVES * WAVE), 0, s, a);
+    hipLaunchKernelGGL((k_rows_overflow<MODE_COUNT, FULL, int32_t>), dim3(over_grid), dim3(ROWS_WAVES * WAVE), 0, s, a);
+    return;
+  }
+  const int32_t nbp = (h->n + 255) / 256;
+  if (h->b_wide) {
+    if (h->n > 0)
+      hipLaunchKernelGGL(k_row_base<int64_t>, dim3(nbp), dim3(256), 0, s, static_cast<const int64_t*>(h->key_pointer), h->sorted_row,
+                         h->n_rows, h->n, static_cast<int64_t*>(h->base_sorted));
+    hipLaunchKernelGGL((k_fill_rows<V, FULL, int64_t>), dim3(ncells_i), dim3(ROWS_FW * WAVE), 0, s, a, static_cast<const int64_t*>(h->base_sorted));
+    hipLaunchKernelGGL((k_rows_overflow<MODE_FILL, FULL, int64_t>), dim3(over_grid), dim3(ROWS_WAVES * WAVE), 0, s, a);
+  } else {
+    if (h->n > 0)
+      hipLaunchKernelGGL(k_row_base<int32_t>, dim3(nbp), dim3(256), 0, s, static_cast<const int32_t*>(h->key_pointer), h->sorted_row,
+                         h->n_rows, h->n, static_cast<int32_t*>(h->base_sorted));
+    hipLaunchKernelGGL((k_fill_rows<V, FULL, int32_t>), dim3(ncells_i), dim3(ROWS_FW * WAVE), 0, s, a, static_cast<const int32_t*>(h->base_sorted));
+    hipLaunchKernelGGL((k_rows_overflow<MODE_FILL, FULL, int32_t>), dim3(over_grid), dim3(ROWS_WAVES * WAVE), 0, s, a);
+  }
+}
+
 // FULL = the list keeps both directions of every pair (the reference GPU class's contract).
 template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(nl_handle_t h, const SweepArgs<T>& a, int32_t ncells_i, hipStream_t s) {
   const int32_t nbp = (h->n + 255) / 256;
@@ -297,6 +348,14 @@ template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(
 template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h, int mode, hipStream_t s) {
   const int32_t owned_layers = h->b_slab ? h->b_mzl - 2 : h->b_mzl;
   const int32_t ncells_i = h->m[0] * h->m[1] * owned_layers;
+  if constexpr (sizeof(T) == 4 && !PBC) {
+    if (h->b_rows) {
+      if (h->b_rows_v == 0) launch_rows<0, FULL>(h, mode, ncells_i, s);
+      else if (h->b_rows_v == 1) launch_rows<1, FULL>(h, mode, ncells_i, s);
+      else launch_rows<2, FULL>(h, mode, ncells_i, s);
+      return;
+    }
+  }
   const SweepArgs<T> a = sweep_args<T>(h);
   if (h->b_use_masks) {
     if (mode == MODE_COUNT) {
@@ -348,8 +407,8 @@ enum { PART_ALL = 0, PART_BEGIN = 1, PART_FINISH = 2 };
 
 // Mask rows for `nb` LDS batches per particle: allocated on first need (a half-shell handle that meets a minimum-image
 // or dense build; a first dense build).
-bool mask_rows_ready(nl_handle_t h, int64_t nb) {
-  const size_t need = (size_t)MASK_ROW_BYTES * (size_t)nb * ((size_t)h->n_max + 64);  // (+64: k_fill_masks reads whole row batches)
+bool mask_rows_ready(nl_handle_t h, int64_t nb, size_t row_bytes = MASK_ROW_BYTES) {
+  const size_t need = row_bytes * (size_t)nb * ((size_t)h->n_max + 64);  // (+64: the expansion kernels read whole row batches)
   if (need > h->dense_masks_limit) return false;
   if (need > h->masks_bytes || !h->masks) {
     if (dev_alloc(h, &h->masks, need) != NL_OK) {
@@ -359,6 +418,19 @@ bool mask_rows_ready(nl_handle_t h, int64_t nb) {
     h->masks_bytes = need;
   }
   return true;
+}
+
+// The fine-row layout needs the two-level binning (k_bin_cells<FINE>) and a fine table that an int32 can index.
+bool rows_layout_ok(nl_handle_t h, int32_t mzl) {
+  const int64_t nrows = (int64_t)h->m[1] * mzl;
+  return h->bin_two_level && nrows <= BIN_MAX_ROWS && h->m[0] <= BIN_FINE_MAX_MX && 4 * (int64_t)h->m[0] * nrows < 2147483000LL;
+}
+// Two particles five or more quarter-planes apart along z have rounded products t = z * ims more than 1 apart, so their
+// distance along z exceeds ms (1 - 8 m 2^-24) (two roundings of t, relative 2^-24 each, at |t| <= 2 m, and the
+// rounding of ims): the pair fails the cut-off test in any rounding of r2 once ms / rc > 1 + 8 m 2^-24 + 2^-20.
+bool rows_margin_ok(nl_handle_t h) {
+  const double ms = h->L[2] / h->m[2];
+  return ms / h->rc >= 1.0 + 8.0 * h->m[2] * 5.9604644775390625e-8 + 9.5367431640625e-7;
 }
 
 // What the handle remembers about the build being enqueued (also set when a captured graph of it is replayed): how the
@@ -378,6 +450,23 @@ void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int
   const bool sparse_enough = mean_stream <= 0.85 * SweepCfg<T>::CAP;  // mean stencil <= 1088: <= 40.3 per cell
   h->b_use_masks = h->b_variant >= 3 && sparse_enough && mask_rows_ready(h, 1);
   h->b_mask_nb = 1;
+  // The fine-row search (nl_rows.hpp): fp32, open box, the two-level binning, and a cell edge that exceeds the cut-off
+  // along z by more than the rounding of the cell hash can hide (rows_margin_ok).  RowsCfg by the mean stencil
+  // stream m = 27 <N/cell>: m + 5 sigma within the LDS buffer, the piece a wave walks + 6 sigma within its hit word.
+  h->b_rows = false;
+  if (sizeof(T) == 4 && h->b_variant >= 3 && !h->pbc && h->rows_env != 0 && rows_layout_ok(h, mzl) && rows_margin_ok(h)) {
+    int v = -1;
+    if (h->rows_env > 0) {
+      v = std::min(h->rows_env, 3) - 1;
+    } else {
+      // (a wave walks 27 of the 36 windows)
+      const double span = mean_stream * 27.0 / 36.0;
+      const int cap[3] = {RowsCfg<0>::CAP, RowsCfg<1>::CAP, RowsCfg<2>::CAP}, bits[3] = {16, 32, 32};
+      for (int k = 0; k < 3 && v < 0; k++)
+        if (mean_stream + 5.0 * std::sqrt(mean_stream) <= cap[k] && span + 6.0 * std::sqrt(span) <= 64.0 * bits[k]) v = k;
+    }
+    if (v >= 0 && mask_rows_ready(h, 1, v == 0 ? 128 : 256)) h->b_rows = true, h->b_rows_v = v, h->b_use_masks = true;
+  }
   if (h->b_variant >= 3 && !sparse_enough && !h->dense_masks_off) {
     // Dense cells: hit masks for up to FD_NB LDS batches per slot instead of a second distance sweep, when the streams
     // (mean + 5 sigma of a Poisson count) fit that many batches and the mask rows fit the memory set aside for them
@@ -429,7 +518,15 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
       if (events) (void)hipEventRecord(ev[NL_STAGE_REORDER], s);
       hipLaunchKernelGGL((k_bin_scatter<T>), dim3(blocks), dim3(BIN_THREADS), 0, s, q, stride, gid, n, h->bin_chunk, g, nrows,
                          rc_arr, rs_arr, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row, h->status, ph);
-      hipLaunchKernelGGL((k_bin_cells<T>), dim3(cells_grid), dim3(256), 0, s, g, nrows, rs_arr,
+      if constexpr (sizeof(T) == 4) {
+        if (h->b_rows) {
+          hipLaunchKernelGGL((k_bin_cells<T, true>), dim3(cells_grid), dim3(256), 0, s, g, nrows, rs_arr,
+                             static_cast<const Pos<T>*>(h->tmp_pos), h->tmp_row, h->cell_start, static_cast<Pos<T>*>(h->sorted),
+                             h->sorted_row, h->sorted_gid, ph);
+          return;
+        }
+      }
+      hipLaunchKernelGGL((k_bin_cells<T, false>), dim3(cells_grid), dim3(256), 0, s, g, nrows, rs_arr,
                          static_cast<const Pos<T>*>(h->tmp_pos), h->tmp_row, h->cell_start, static_cast<Pos<T>*>(h->sorted),
                          h->sorted_row, h->sorted_gid, ph);
     };
@@ -744,6 +841,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : 3;
     if (const char* v = getenv("NL_ISPLIT")) h->isplit_env = std::max(0, atoi(v));
     if (const char* v = getenv("NL_DENSE_MASKS")) h->dense_masks_off = atoi(v) == 0;
+    if (const char* v = getenv("NL_ROWS")) h->rows_env = std::max(-1, std::min(atoi(v), 3));
     if (const char* v = getenv("NL_OFFSET_WIDTH")) h->offset_width = atoi(v) == 64 ? 64 : atoi(v) == 32 ? 32 : 0;
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_GRAPH")) h->use_graph = atoi(v) != 0;
@@ -819,7 +917,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   HIPCHK(h, hipMemset(h->dbg_buf, 0, 8 * (64 + 4 * 4096)));
   if ((rc = dev_alloc(h, &h->cell_count, 4 * ((size_t)h->ncell + 64 + 2 * (size_t)h->m[1] * h->m[2])))) return rc;
   h->row_count = h->cell_count + h->ncell + 32;
-  if ((rc = dev_alloc(h, &h->cell_start, 4 * ((size_t)h->ncell + 32)))) return rc;
+  if ((rc = dev_alloc(h, &h->cell_start, 4 * (4 * (size_t)h->ncell + 32)))) return rc;  // (cell_start, or the fine-row table: 4 M + 1)
   const size_t nblk = std::max<size_t>(n, (size_t)h->ncell) / SCAN_BLOCK + 2;
   if ((rc = dev_alloc(h, &h->block_sum, 8 * nblk))) return rc;
   if ((rc = dev_alloc(h, &h->totals, 8 * 4))) return rc;
@@ -1166,7 +1264,7 @@ int nl_get_build_info(nl_handle_t h, int32_t info[8]) {
   for (int k = 4; k < 8; k++) info[k] = 0;
   info[4] = h->b_wide ? 64 : 32;
   info[5] = h->b_mask_nb;
-  info[6] = 0;
+  info[6] = h->b_rows ? 1 + h->b_rows_v : 0;  // fine-row search: the cell table of nl_get_sorted is the fine-row table
   info[0] = h->b_use_masks ? 1 : 0;
   info[1] = h->sweep_variant;
   info[2] = h->dtype == NL_F32 ? SweepCfg<float>::CAP : SweepCfg<double>::CAP;

@@ -559,30 +559,48 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
   }
 }
 
-template <typename T>
+// FINE (nl_rows.hpp, fp32 open box): the row's particles are sorted by (quarter of the cell along z, x-cell) instead of
+// the x-cell alone: the row of x-cells becomes four FINE ROWS, each contiguous in x, and the table written is
+// fine_start[(r * mx + cx) * 4 + qz] (4 M + 1 entries) in the place of cell_start.  The quarter a particle lies in
+// comes from the fraction of the same rounded product t = z * ims the reference truncates for the cell index
+// (neighlist_cpu.hpp:51-59): floor(4 (t - trunc(t))) -- a negative fraction (a particle just below the box: the
+// reference's truncation files t = -0.3 into cell 0) counts as quarter 0.
+constexpr int BIN_FINE_MAX_MX = 2048;
+template <typename T, bool FINE = false>
 __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, const int32_t* __restrict__ row_start,
                                                    const Pos<T>* __restrict__ tmp, const int32_t* __restrict__ tmp_row,
                                                    int32_t* __restrict__ cell_start, Pos<T>* __restrict__ sorted,
                                                    int32_t* __restrict__ sorted_row, int32_t* __restrict__ sorted_gid,
                                                    BinPhase ph) {
-  __shared__ int32_t cnt[BIN_MAX_MX];
+  __shared__ int32_t cnt[FINE ? 4 * BIN_FINE_MAX_MX : BIN_MAX_MX];
   __shared__ int32_t wsum[4];
   __shared__ int32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int32_t bx = blockIdx.x, mx = g.m[0];
+  const int32_t nb = FINE ? 4 * mx : mx;  // bins of the row
   const int32_t r = bx < ph.cells_n0 ? ph.cells_row0 + bx : ph.cells_row1 + (bx - ph.cells_n0);
   const int32_t beg = row_start[r], end = row_start[r + 1];
-  for (int32_t c = tid; c < mx; c += 256) cnt[c] = 0;
+  for (int32_t c = tid; c < nb; c += 256) cnt[c] = 0;
   if (tid == 0) carry_s = 0;
   __syncthreads();
   // x-cell exactly as local_cell computes it (the particle passed the range checks in k_bin_rows)
-  auto xcell = [&](T x) {
+  auto xcell1 = [&](T x) {
     const T tx = mul_rn(x, g.ims[0]);
     int32_t v = (int32_t)tx;
     if (g.pbc && tx < (T)0 && (T)v != tx) v -= 1;
     if (v < 0) v += mx;
     if (v >= mx) v -= mx;
     return v;
+  };
+  auto quarter = [&](T q, T ims) {  // first two fractional bits of q * ims (the subtraction is exact)
+    const T t = mul_rn(q, ims);
+    const T f = sub_rn(t, (T)(int32_t)t);
+    return (f >= (T)0.25 ? 1 : 0) + (f >= (T)0.5 ? 1 : 0) + (f >= (T)0.75 ? 1 : 0);
+  };
+  auto bin_of = [&](const Pos<T>& p) {
+    const int32_t c = xcell1(p.x);
+    if constexpr (FINE) return quarter(p.z, g.ims[2]) * mx + c;
+    else return c;
   };
   // The row's particles stay in registers between the histogram and the placement (rows of up to BC_KEEP * 256: one
   // read of tmp instead of two, and all of a thread's loads in one round trip); longer rows are read twice.
@@ -604,15 +622,15 @@ __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, con
     }
 #pragma unroll
     for (int u = 0; u < BC_KEEP; u++)
-      if (beg + tid + u * 256 < end) atomicAdd(&cnt[xcell(pk[u].x)], 1);
+      if (beg + tid + u * 256 < end) atomicAdd(&cnt[bin_of(pk[u])], 1);
   } else {
-    for (int32_t k = beg + tid; k < end; k += 256) atomicAdd(&cnt[xcell(tmp[k].x)], 1);
+    for (int32_t k = beg + tid; k < end; k += 256) atomicAdd(&cnt[bin_of(tmp[k])], 1);
   }
   __syncthreads();
-  // exclusive scan of cnt[0..mx) in place, 256 entries at a time, and the row's slice of cell_start
-  for (int32_t base = 0; base < mx; base += 256) {
+  // exclusive scan of cnt[0..nb) in place, 256 entries at a time, and the row's slice of cell_start
+  for (int32_t base = 0; base < nb; base += 256) {
     const int32_t c = base + tid;
-    const int32_t v = c < mx ? cnt[c] : 0;
+    const int32_t v = c < nb ? cnt[c] : 0;
     const int32_t inc = wave_incl_scan(v, lane);
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
@@ -620,17 +638,19 @@ __global__ void __launch_bounds__(256) k_bin_cells(Grid<T> g, int32_t nrows, con
     for (int k = 0; k < w; k++) woff += wsum[k];
     const int32_t carry = carry_s;
     const int32_t excl = carry + woff + inc - v;
-    if (c < mx) {
+    if (c < nb) {
       cnt[c] = excl;
-      cell_start[(size_t)r * mx + c] = beg + excl;
+      // (FINE: bin c = quarter * mx + x-cell is filed at (r * mx + x-cell) * 4 + quarter: rows_fine_index)
+      if constexpr (FINE) cell_start[((size_t)r * mx + (c % mx)) * 4 + c / mx] = beg + excl;
+      else cell_start[(size_t)r * nb + c] = beg + excl;
     }
     __syncthreads();
     if (tid == 255) carry_s = carry + woff + inc;
     __syncthreads();
   }
-  if (r == nrows - 1 && tid == 0) cell_start[(size_t)nrows * mx] = end;
+  if (r == nrows - 1 && tid == 0) cell_start[(size_t)nrows * nb] = end;
   auto place = [&](Pos<T> p, int32_t row_of) {
-    const int32_t dst = beg + atomicAdd(&cnt[xcell(p.x)], 1);
+    const int32_t dst = beg + atomicAdd(&cnt[bin_of(p)], 1);
     if (g.pbc) {  // minimum-image mode: a wrapped x index means the particle is stored at its image
       const T tx = mul_rn(p.x, g.ims[0]);
       int32_t v = (int32_t)tx;
@@ -1860,6 +1880,7 @@ __global__ void __launch_bounds__(FD_WAVES* WAVE) k_fill_dense(SweepArgs<T> a, c
 }  // namespace nl
 
 #include "nl_lean.hpp"
+#include "nl_rows.hpp"
 
 namespace nl {
 

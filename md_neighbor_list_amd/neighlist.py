@@ -299,10 +299,13 @@ class NeighListGPU:
 
     # ------------------------------------------------------------------ introspection
     def sorted_state(self):
-        """(cell_start, sorted_row) of the last build -- for tests of the hash/sort stage."""
+        """(cell_start, sorted_row) of the last build -- for tests of the hash/sort stage.  In a fine-row build
+        (build_info()['fine_rows'] > 0) the table has 4 entries per cell: [(row * mx + cx) * 4 + quarter], the four
+        fine rows (quarters of the cell along z) of every row of x-cells."""
         cs, sp, sr, ncl = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
         check(self._lib.nl_get_sorted(self._h, C.byref(cs), C.byref(sp), C.byref(sr), C.byref(ncl)), "nl_get_sorted")
-        return (_as_tensor(cs.value, (ncl.value + 1,), "<i4", self, self.device),
+        entries = ncl.value * (4 if self.build_info()["fine_rows"] else 1) + 1
+        return (_as_tensor(cs.value, (entries,), "<i4", self, self.device),
                 _as_tensor(sr.value, (self._n,), "<i4", self, self.device))
 
     def profile_stages(self, q, reps=10):
@@ -317,11 +320,12 @@ class NeighListGPU:
 
     def build_info(self):
         """{'masks': bool, 'variant': int, 'lds_batch': int, 'cus': int, 'offset_bits': 32 | 64, 'mask_rows': int,
-        'half_shell': bool} of the last build (masks: the list was expanded from hit masks; mask_rows > 1: dense build)."""
+        'fine_rows': 0 | 1 + RowsCfg} of the last build (masks: the list was expanded from hit masks; mask_rows > 1: dense
+        build; fine_rows: the fine-row search of nl_rows.hpp)."""
         info = (C.c_int32 * 8)()
         check(self._lib.nl_get_build_info(self._h, C.byref(info)), "nl_get_build_info")
         return {"masks": bool(info[0]), "variant": int(info[1]), "lds_batch": int(info[2]), "cus": int(info[3]),
-                "offset_bits": int(info[4]), "mask_rows": int(info[5]), "half_shell": bool(info[6])}
+                "offset_bits": int(info[4]), "mask_rows": int(info[5]), "fine_rows": int(info[6])}
 
     def profile_last_build(self, reps=10):
         """Same for the last build (also a slab build); its position/id tensors are kept alive by this object."""

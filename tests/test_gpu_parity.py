@@ -81,9 +81,13 @@ def test_two_times_cutoff_fp64():
     assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
 
 
-def test_hash_and_sort_stage():
-    """a3-a5: every particle lands in the cell the reference's GenHash gives it (neighlist_cpu.hpp:51-59)."""
+@pytest.mark.parametrize("rows", [0, 1])
+def test_hash_and_sort_stage(rows, monkeypatch):
+    """a3-a5: every particle lands in the cell the reference's GenHash gives it (neighlist_cpu.hpp:51-59); rows = 1: in
+    the fine-row layout of nl_rows.hpp (the cell's particles as four quarters along z)."""
     import torch
+
+    monkeypatch.setenv("NL_ROWS", str(rows))
 
     q, box = inputs.uniform_box(100000, 1.0, np.float32, seed=41)
     q[:50, :3] = np.nextafter(np.float32(box[0]), np.float32(0))  # rounds up to the box edge -> wraps to cell 0
@@ -91,11 +95,30 @@ def test_hash_and_sort_stage():
     nl, nop, kp, sl = gpu_build(q, 3.3, box)
     assert tuple(nl.mesh_size) == tuple(mesh)
     cell_start, sorted_row = (t.cpu().numpy() for t in nl.sorted_state())
+    if nl.build_info()["fine_rows"]:
+        # the fine-row table keeps the four quarters of a cell side by side, [(row * mx + cx) * 4 + quarter]; the particles
+        # are sorted by (row, quarter, cx): back to that order
+        mx = int(mesh[0])
+        t = cell_start[:-1].reshape(-1, mx, 4).transpose(0, 2, 1).reshape(-1)
+        cell_start = np.append(t, cell_start[-1])
     assert cell_start[0] == 0 and cell_start[-1] == len(q) and np.all(np.diff(cell_start) >= 0)
     assert np.array_equal(np.sort(sorted_row), np.arange(len(q)))
-    cell_of_slot = np.repeat(np.arange(len(cell_start) - 1), np.diff(cell_start))
+    bin_of_slot = np.repeat(np.arange(len(cell_start) - 1), np.diff(cell_start))
+    if nl.build_info()["fine_rows"]:
+        # bins in the order (row * 4 + quarter) * mx + cx -- every row of x-cells as four fine rows (quarters in z)
+        mx = mesh[0]
+        fine_row, cx = np.divmod(bin_of_slot, mx)
+        cell_of_slot = (fine_row // 4) * mx + cx
+        # the quarter a particle lies in: fraction of the product the reference truncates (GenHash)
+        ms = (np.asarray(box, dtype=np.float64) / np.asarray(mesh)).astype(np.float32)  # neighlist_cpu.hpp:389-391, 409-411
+        ims = (1.0 / ms.astype(np.float64)).astype(np.float32)
+        t = q[sorted_row, :3].astype(np.float32) * ims
+        frac = t[:, 2] - np.trunc(t[:, 2])
+        assert np.array_equal(fine_row % 4, np.clip(np.floor(frac * np.float32(4.0)), 0, 3).astype(np.int64))
+    else:
+        cell_of_slot = bin_of_slot
     assert np.array_equal(cells[sorted_row], cell_of_slot)
-    assert np.array_equal(np.bincount(cells, minlength=len(cell_start) - 1), np.diff(cell_start))
+    assert np.array_equal(np.bincount(cells, minlength=int(np.prod(mesh))), np.bincount(cell_of_slot, minlength=int(np.prod(mesh))))
     del torch
 
 
@@ -989,3 +1012,57 @@ def test_cells_handed_to_the_batched_search():
         fkp, flst, fcnt = (t.cpu().numpy() for t in nl.full_csr())
         assert np.array_equal(fcnt, want_cnt) and np.array_equal(fkp.astype(np.int64), want_kp), (n, clustered)
         assert np.array_equal(canonical_csr(fkp, flst), want_list), (n, clustered)
+
+
+@pytest.mark.parametrize("rows", [-1, 1, 2, 3, 0])
+def test_fine_row_search_configurations(rows, monkeypatch):
+    """NL_ROWS: the fine-row search of nl_rows.hpp (-1: where a build qualifies, RowsCfg by density) forced to each of
+    its three configurations (1: 16-bit hit words; 2, 3: 32-bit words, larger LDS streams) and switched off (0, the
+    default: the 27-cell path) -- same lists.  Boxes: cubic and not, a mesh of 3 along x and y (every cell at the periodic
+    wrap in x: windows of two pieces), sparse, a cluster (cells whose stream exceeds the LDS buffer: k_rows_overflow),
+    particles outside the box (the reference files them by the truncated, wrapped cell index), half and full list."""
+    import torch
+
+    monkeypatch.setenv("NL_ROWS", str(rows))
+    rng = np.random.default_rng(70 + rows)
+    cases = [(50000, (36.84, 36.84, 36.84), 3.3, ""), (9000, (25.0, 14.0, 19.0), 3.1, ""), (4096, (16.0, 16.0, 16.0), 3.3, ""),
+             (9000, (10.5, 10.5, 40.0), 3.3, ""), (3000, (60.0, 60.0, 60.0), 3.3, ""), (60000, (40.0, 40.0, 40.0), 3.3, "cluster"),
+             (30000, (30.0, 33.5, 36.5), 3.3, "outside"), (120000, (50.0, 61.0, 46.0), 3.0, "cluster2")]
+    for n, box, rc, kind in cases:
+        q, box = inputs.uniform_box(n, dtype=np.float32, seed=int(rng.integers(1 << 30)), box=box)
+        if kind.startswith("cluster"):
+            k = int((0.12 if kind == "cluster" else 0.02) * n)
+            q[:k, :3] = (np.array(box) * 0.5 + rng.uniform(-0.9 * rc, 0.9 * rc, size=(k, 3))).astype(np.float32)
+        if kind == "outside":  # up to 0.9 box lengths outside, on every side
+            k = n // 20
+            q[:k, :3] += (rng.choice([-1.0, 1.0], size=(k, 3)) * rng.uniform(0.0, 0.9, size=(k, 3)) * np.array(box)).astype(np.float32)
+        ref = _po().build(q, rc, box)
+        nl, nop, kp, sl = gpu_build(q, rc, box)
+        info = nl.build_info()
+        if rows >= 0:
+            assert info["fine_rows"] == rows, (kind, info)
+        assert int(kp[-1]) == ref.npairs, (n, kind, info)
+        assert np.array_equal(nop, ref.number_of_partners), (n, kind, info)
+        assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), (n, kind, info)
+        assert nl.list_checksum() == (ref.hash(), ref.npairs)
+        nl.set_full_list(True)
+        nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+        want_kp, want_list, want_cnt = _full_from_half(ref)
+        fkp, flst, fcnt = (t.cpu().numpy() for t in nl.full_csr())
+        assert np.array_equal(fcnt, want_cnt) and np.array_equal(fkp.astype(np.int64), want_kp), (n, kind, info)
+        assert np.array_equal(canonical_csr(fkp, flst), want_list), (n, kind, info)
+
+
+def test_fine_row_search_is_not_taken_without_margin(monkeypatch):
+    """A box whose cell edge equals the cut-off along z (Lz / rc an integer) keeps the 27-cell search: two particles five
+    quarter-planes apart may then be within the cut-off after rounding (rows_margin_ok in nl_api.hip)."""
+    monkeypatch.setenv("NL_ROWS", "-1")
+    q, box = inputs.uniform_box(40000, dtype=np.float32, seed=5, box=(33.0, 33.0, 33.0))
+    ref = _po().build(q, 3.3, box)
+    nl, nop, kp, sl = gpu_build(q, 3.3, box)
+    assert nl.build_info()["fine_rows"] == 0 and nl.build_info()["masks"]
+    assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+    q, box = inputs.uniform_box(40000, dtype=np.float32, seed=5, box=(33.0, 33.0, 33.9))  # the margin matters along z only
+    nl, nop, kp, sl = gpu_build(q, 3.3, box)
+    assert nl.build_info()["fine_rows"] == 1
+    assert np.array_equal(canonical_csr(kp, sl), _po().build(q, 3.3, box).canonical().sorted_list)
