@@ -33,6 +33,13 @@ namespace nl {
 #ifndef NL_ROWS_SHARES   // 1: the cell's particles in four equal shares; 0: wave w of the COUNT sweep takes quarter w
 #define NL_ROWS_SHARES 1
 #endif
+// timing experiments only (wrong lists; profiles/r03_fine_rows_investigation.txt)
+#ifndef NL_ROWS_DIAG  // 1 = no hit-word stores, 2 = no count stores, 4 = no tile loop
+#define NL_ROWS_DIAG 0
+#endif
+#ifndef NL_ROWS_EXIT  // the COUNT sweep leaves after 1 = its first instruction, 2 = the window table, 3 = the DMA issue, 4 = the barrier
+#define NL_ROWS_EXIT 0
+#endif
 #ifndef NL_ROWS_GATHER   // 0: the stream is staged window by window
 #define NL_ROWS_GATHER 1
 #endif
@@ -389,9 +396,6 @@ __global__ void __launch_bounds__(ROWS_WAVES* WAVE, RowsCfg<V>::WS) __attribute_
     t_prev = now;
   };
 #endif
-#ifndef NL_ROWS_EXIT  // timing experiments only (wrong lists): the COUNT sweep leaves after 1 = its first instruction,
-#define NL_ROWS_EXIT 0   // 2 = the window table, 3 = the DMA issue, 4 = the barrier
-#endif
   if (NL_ROWS_EXIT == 1) return;
   int32_t cx, cy, cz;
   rows_cell_of_block(a, cx, cy, cz);
@@ -465,9 +469,6 @@ __global__ void __launch_bounds__(ROWS_WAVES* WAVE, RowsCfg<V>::WS) __attribute_
       }
 #if NL_STAMP
       stamp(4);  // rows_group: readlanes, tile loop, words and counts
-#endif
-#ifndef NL_ROWS_DIAG  // timing experiments only (wrong lists): 1 = no hit-word stores, 2 = no count stores, 4 = no tile loop
-#define NL_ROWS_DIAG 0
 #endif
       if (lane < gcount && (!(NL_ROWS_DIAG & 2) || a.wide == 7)) a.count[row_l] = mine;
 #pragma unroll
