@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batches", type=int, default=7,
+                    help="timed batches of --steps builds each (SURVEY.md section 8d: the reference times LOOP = 100 builds, make_list.cu:20,124-132); "
+                         "ms_per_step is the median batch, min and max are reported next to it")
     ap.add_argument("--workload", default="auto", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg5", "weak"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg4-baseline", action="store_true",
@@ -294,26 +297,29 @@ def main():
     for _ in range(args.warmup):
         step()
     nl.synchronize()  # surfaces any error (capacity, out of box) before timing
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # every batch: exactly --steps builds between a barrier + device synchronisation on both sides
+    batch_s = []
+    for _ in range(max(1, args.batches)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        fence()
+        batch_s.append(time.perf_counter() - t0)
     nl.synchronize()
 
     npairs_local = nl.half_number_of_pairs()
     cs_local, _ = nl.list_checksum()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    t = torch.tensor(batch_s, dtype=torch.float64, device=red_dev)
     p = torch.tensor([npairs_local, cs_local >> 32, cs_local & 0xFFFFFFFF], dtype=torch.int64, device=red_dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # a batch takes as long as its slowest rank
         dist.all_reduce(p, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
+    batch_ms = sorted(float(x) / args.steps * 1e3 for x in t.tolist())
     npairs = int(p[0].item())
     checksum = ((int(p[1].item()) << 32) + int(p[2].item())) & ((1 << 64) - 1)  # wrapping sum of the ranks' checksums
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step = batch_ms[len(batch_ms) // 2]  # the median batch
 
     out = None
     if rank == 0:
@@ -358,6 +364,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_min": round(batch_ms[0], 4), "ms_per_step_max": round(batch_ms[-1], 4), "batches": len(batch_ms),
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,

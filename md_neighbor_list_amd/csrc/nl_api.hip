@@ -75,8 +75,9 @@ struct nl_handle_s {
   size_t masks_bytes = 0;          // size of the masks allocation
   int32_t b_isplit = 1;            // this build, two-sweep path: workgroups per cell
   int isplit_env = 0;              // NL_ISPLIT: 0 = by density
-  int rows_env = 0;                // NL_ROWS: 0 (default) = the 27-cell path, -1 = the fine-row search where a build qualifies,
-                                   // 1..3 = force RowsCfg<V - 1> where it qualifies (tests)
+  int rows_env = -1;               // NL_ROWS: -1 (default) = the fine-row search where the 27-cell path would need several LDS batches
+                                   // per cell (denser than 40.3 particles per cell), 0 = never, 1..3 = RowsCfg<V - 1> wherever a
+                                   // build qualifies (tests), 4 = wherever a build qualifies, RowsCfg by density (sweeps)
   bool b_rows = false;             // this build: fine rows (k_bin_cells<FINE>, k_sweep_rows_f32, k_fill_rows); the cell table is
   int b_rows_v = 0;                // fine_start (4 M + 1 entries); RowsCfg of the build
   bool dense_masks_off = false;    // NL_DENSE_MASKS=0: dense builds use two distance sweeps (the round-1 path)
@@ -456,9 +457,12 @@ void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int
   h->b_rows = false;
   if (sizeof(T) == 4 && h->b_variant >= 3 && !h->pbc && h->rows_env != 0 && rows_layout_ok(h, mzl) && rows_margin_ok(h)) {
     int v = -1;
-    if (h->rows_env > 0) {
-      v = std::min(h->rows_env, 3) - 1;
-    } else {
+    if (h->rows_env > 0 && h->rows_env <= 3) {
+      v = h->rows_env - 1;
+    } else if (h->rows_env == 4 || !sparse_enough) {
+      // (at the BASELINE densities the 27-cell sweep is the faster one: 0.512 against 0.570 ms at config 2; from 40.3
+      // particles per cell on its streams no longer fit one LDS batch: 0.97 against 0.60 ms at rho = 1.1 --
+      // profiles/r03_density_sweep.txt)
       // (a wave walks 27 of the 36 windows)
       const double span = mean_stream * 27.0 / 36.0;
       const int cap[3] = {RowsCfg<0>::CAP, RowsCfg<1>::CAP, RowsCfg<2>::CAP}, bits[3] = {16, 32, 32};
@@ -841,7 +845,7 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     if (const char* v = getenv("NL_SWEEP_VARIANT")) h->sweep_variant = atoi(v) <= 1 ? 1 : 3;
     if (const char* v = getenv("NL_ISPLIT")) h->isplit_env = std::max(0, atoi(v));
     if (const char* v = getenv("NL_DENSE_MASKS")) h->dense_masks_off = atoi(v) == 0;
-    if (const char* v = getenv("NL_ROWS")) h->rows_env = std::max(-1, std::min(atoi(v), 3));
+    if (const char* v = getenv("NL_ROWS")) h->rows_env = std::max(-1, std::min(atoi(v), 4));
     if (const char* v = getenv("NL_OFFSET_WIDTH")) h->offset_width = atoi(v) == 64 ? 64 : atoi(v) == 32 ? 32 : 0;
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_GRAPH")) h->use_graph = atoi(v) != 0;

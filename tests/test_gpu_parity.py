@@ -300,6 +300,47 @@ def test_pairs_at_the_cutoff_fp32(variant, monkeypatch):
     assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
 
 
+@pytest.mark.parametrize("variant", SWEEP_VARIANTS)
+def test_pairs_at_the_cutoff_fp64(variant, monkeypatch):
+    """The screened fp64 search (fp32 screen + the reference's fp64 expression inside an error band, nl_kernels.hpp
+    "screened fp64 search") under adversarial input: partners at rc (1 +- k 2^-52) -- the last bits of the exact decision --
+    and at rc (1 +- k 2^-24), k up to 96 -- on both sides of the band's edges -- around centres spread over a 300-wide box,
+    where the coordinates relative to the cell centre and hence R_i + R_j of the band formula are as large as they get
+    (and the absolute coordinates have lost 8 bits to the box size).  The decision must be the reference's,
+    neighlist_cpu.hpp:219-223: half and full list."""
+    import torch
+
+    monkeypatch.setenv("NL_SWEEP_VARIANT", str(variant))
+    rng = np.random.default_rng(78)
+    rc, L = 3.3, 300.0
+    nc = 20000
+    centres = rng.uniform(4.0, L - 4.0, size=(nc, 3))
+    # a third of the centres in the far corners of their cells (largest L1 norm relative to the cell centre)
+    ms = L / int(L / rc)
+    corner = (np.floor(centres[: nc // 3] / ms) + rng.choice([0.002, 0.998], size=(nc // 3, 3))) * ms
+    centres[: nc // 3] = corner
+    d = rng.normal(size=(nc, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k52 = rng.integers(-8, 9, size=(nc, 1)) * 2.0 ** -52
+    k24 = rng.integers(-96, 97, size=(nc, 1)) * 2.0 ** -24
+    scale = 1.0 + np.where(rng.random((nc, 1)) < 0.5, k52, k24)
+    q = np.concatenate([centres, centres + d * rc * scale]).astype(np.float64)
+    q = np.clip(q, 0.0, np.nextafter(L, 0.0))
+    q = q[rng.permutation(len(q))]
+    box = (L, L, L)
+    ref = _po().build(q, rc, box)
+    nl, nop, kp, sl = gpu_build(q, rc, box)
+    assert int(kp[-1]) == ref.npairs
+    assert np.array_equal(nop, ref.number_of_partners)
+    assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+    nl.set_full_list(True)
+    nl.MakeNeighList(torch.from_numpy(q).cuda(), len(q))
+    want_kp, want_list, want_cnt = _full_from_half(ref)
+    fkp, flst, fcnt = (t.cpu().numpy() for t in nl.full_csr())
+    assert np.array_equal(fcnt, want_cnt) and np.array_equal(fkp.astype(np.int64), want_kp)
+    assert np.array_equal(canonical_csr(fkp, flst), want_list)
+
+
 def _full_from_half(h):
     """Symmetrised oracle list: (key_pointer, canonical list, counts) of the FULL neighbour list."""
     n = len(h.key_pointer) - 1
@@ -1014,11 +1055,11 @@ def test_cells_handed_to_the_batched_search():
         assert np.array_equal(canonical_csr(fkp, flst), want_list), (n, clustered)
 
 
-@pytest.mark.parametrize("rows", [-1, 1, 2, 3, 0])
+@pytest.mark.parametrize("rows", [4, 1, 2, 3, 0])
 def test_fine_row_search_configurations(rows, monkeypatch):
-    """NL_ROWS: the fine-row search of nl_rows.hpp (-1: where a build qualifies, RowsCfg by density) forced to each of
-    its three configurations (1: 16-bit hit words; 2, 3: 32-bit words, larger LDS streams) and switched off (0, the
-    default: the 27-cell path) -- same lists.  Boxes: cubic and not, a mesh of 3 along x and y (every cell at the periodic
+    """NL_ROWS: the fine-row search of nl_rows.hpp (default -1: in dense boxes; 4: wherever a build qualifies, RowsCfg by
+    density) forced to each of its three configurations (1: 16-bit hit words; 2, 3: 32-bit words, larger LDS streams)
+    and switched off (0: the 27-cell path) -- same lists.  Boxes: cubic and not, a mesh of 3 along x and y (every cell at the periodic
     wrap in x: windows of two pieces), sparse, a cluster (cells whose stream exceeds the LDS buffer: k_rows_overflow),
     particles outside the box (the reference files them by the truncated, wrapped cell index), half and full list."""
     import torch
@@ -1039,7 +1080,7 @@ def test_fine_row_search_configurations(rows, monkeypatch):
         ref = _po().build(q, rc, box)
         nl, nop, kp, sl = gpu_build(q, rc, box)
         info = nl.build_info()
-        if rows >= 0:
+        if rows <= 3:
             assert info["fine_rows"] == rows, (kind, info)
         assert int(kp[-1]) == ref.npairs, (n, kind, info)
         assert np.array_equal(nop, ref.number_of_partners), (n, kind, info)
@@ -1053,10 +1094,29 @@ def test_fine_row_search_configurations(rows, monkeypatch):
         assert np.array_equal(canonical_csr(fkp, flst), want_list), (n, kind, info)
 
 
+def test_dense_boxes_take_the_fine_row_search_by_default():
+    """From 40.3 particles per cell on the 27-cell streams no longer fit one LDS batch and the default path is the
+    fine-row search (RowsCfg by density): 45 and 75 particles per cell, half and full list, against the oracle."""
+    import torch
+
+    for n, box, want in ((45000, (35.9, 35.9, 35.9), 2), (75000, (35.9, 35.9, 35.9), 3)):
+        q, box = inputs.uniform_box(n, dtype=np.float32, seed=61, box=box)
+        ref = _po().build(q, 3.3, box)
+        nl, nop, kp, sl = gpu_build(q, 3.3, box)
+        assert nl.build_info()["fine_rows"] == want, nl.build_info()
+        assert np.array_equal(nop, ref.number_of_partners)
+        assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list)
+        nl.set_full_list(True)
+        nl.MakeNeighList(torch.from_numpy(q).cuda(), n)
+        want_kp, want_list, want_cnt = _full_from_half(ref)
+        fkp, flst, fcnt = (t.cpu().numpy() for t in nl.full_csr())
+        assert np.array_equal(fcnt, want_cnt) and np.array_equal(canonical_csr(fkp, flst), want_list)
+
+
 def test_fine_row_search_is_not_taken_without_margin(monkeypatch):
     """A box whose cell edge equals the cut-off along z (Lz / rc an integer) keeps the 27-cell search: two particles five
     quarter-planes apart may then be within the cut-off after rounding (rows_margin_ok in nl_api.hip)."""
-    monkeypatch.setenv("NL_ROWS", "-1")
+    monkeypatch.setenv("NL_ROWS", "4")
     q, box = inputs.uniform_box(40000, dtype=np.float32, seed=5, box=(33.0, 33.0, 33.0))
     ref = _po().build(q, 3.3, box)
     nl, nop, kp, sl = gpu_build(q, 3.3, box)
