@@ -213,9 +213,10 @@ def main():
     ap.add_argument("--no-cfg4-baseline", action="store_true",
                     help="N = 1: skip the extra measurement of the 33.5 M box on one device (the N = 1 point of the strong-scaling series)")
     ap.add_argument("--profile-reps", type=int, default=10)
-    ap.add_argument("--dist", default="torch", choices=["torch", "cabi"],
-                    help="N > 1: halo exchange by torch.distributed p2p around nl_make_list_slab (md_neighbor_list_amd/slab.py), or the "
-                         "whole decomposed build inside the library (nl_make_list_distributed: pack kernel, counts, RCCL send/recv)")
+    ap.add_argument("--dist", default="cabi", choices=["cabi", "torch"],
+                    help="N > 1: the whole decomposed build inside the library behind the C ABI (default: nl_make_list_distributed -- pack "
+                         "kernel, fixed-capacity halo messages over RCCL, unpack, slab build; no host synchronisation per build), or the halo "
+                         "exchange by torch.distributed p2p around nl_make_list_slab (md_neighbor_list_amd/slab.py)")
     args = ap.parse_args()
 
     import torch

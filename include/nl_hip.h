@@ -175,9 +175,13 @@ int nl_make_list_slab_finish(nl_handle_t h, void* stream, int sync);
  *   for q_capacity rows: the ghosts are written behind the owned rows.  Every owned particle must lie in the rank's
  *   layers (NL_ERR_DOMAIN otherwise: migrating particles between ranks is the caller's job); NL_ERR_CAPACITY when
  *   owned + ghosts exceed q_capacity or the handle's n_max.  Rows (nl_get_half_csr ...) are those of the owned
- *   particles and hold global ids, as after nl_make_list_slab.  Waits for the pack kernel and the counts (two host
- *   synchronisations per build) before it returns, also with sync == 0.
- * nl_distributed_ghosts: the ghost counts of the last build (rows [n_owned, n_owned + lo) and the hi rows behind). */
+ *   particles and hold global ids, as after nl_make_list_slab.  With sync == 0 a steady-state build returns without
+ *   waiting for the device: the boundary layers travel in messages of negotiated capacity with their counts in a header,
+ *   the ghost counts stay on the device (nl_dist.inc).  The first build of a communicator, and the build after one whose
+ *   layer outgrew its message (that one reports NL_ERR_CAPACITY at its synchronisation; with sync == 1 it renegotiates and
+ *   repeats itself), exchange the counts through the host.
+ * nl_distributed_ghosts: the ghost counts of the last build (rows [n_owned, n_owned + lo) and the hi rows behind); waits for
+ *   that build. */
 typedef struct nl_comm_s* nl_comm_t;
 #define NL_UNIQUE_ID_BYTES 128
 typedef int (*nl_sendrecv_fn)(void* user, int peer_to, const void* send, size_t send_bytes, int peer_from, void* recv,

@@ -145,6 +145,11 @@ struct nl_handle_s {
   int b_variant = 3;         // sweep variant of this build (a full build uses 1 or 3 only)
   const void* b_q = nullptr;
   const int32_t* b_gid = nullptr;
+  // nl_make_list_distributed: the ghost counts of the build live on the device (b_dyn[0], b_dyn[1]; n is an upper bound);
+  // dyn_host: where their pinned copy (words 2, 3) and the exchange's error flags (word 4) arrive with the build's result
+  const int32_t* b_dyn = nullptr;
+  int32_t b_n_est = 0;             // particles expected (owned + the previous build's ghosts): path selection only
+  const int32_t* dyn_host = nullptr;
 };
 
 namespace {
@@ -494,7 +499,7 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
                   int32_t n_ghost_lo = 0) {
   const Grid<T> g = make_grid<T>(h, n_rows, z_lo, mzl, slab);
   const int64_t ncl = (int64_t)h->m[0] * h->m[1] * mzl;
-  set_build_state<T>(h, q_dev, stride, gid, n, z_lo, mzl, slab);
+  set_build_state<T>(h, q_dev, stride, gid, h->b_dyn ? h->b_n_est : n, z_lo, mzl, slab);
   const int32_t nbp = (n + 255) / 256;
   const T* q = static_cast<const T*>(q_dev);
 
@@ -537,7 +542,7 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
     if (!split) {
       HIPCHK(h, hipMemsetAsync(h->cell_count + h->ncell, 0, sizeof(int32_t) * (size_t)(32 + nrows), s));
       if (ev) HIPCHK(h, hipEventRecord(ev[NL_STAGE_HASH], s));
-      const BinPhase all = {0, n, nrows, 0, 0, 0, nrows, nrows, -1};
+      const BinPhase all = {0, n, nrows, 0, 0, 0, nrows, nrows, -1, h->b_dyn};
       run_pass(all, h->row_count, h->row_start, nrows, ev != nullptr);
     } else if (part == PART_BEGIN) {
       // owned particles: rows of the layers 1 .. mzl-2, placed behind the n_ghost_lo particles of ghost layer 0
@@ -647,7 +652,11 @@ int finish(nl_handle_t h, bool may_grow) {
     HIPCHK(h, hipStreamSynchronize(h->last_stream));
     st = h->host->status;
   }
-  const int err = status_to_error(st);
+  int err = status_to_error(st);
+  if (h->b_dyn && h->dyn_host) {  // a decomposed build: its ghost counts, and whether the exchange held what was sent
+    h->n = h->n_rows + h->dyn_host[2] + h->dyn_host[3];
+    if (!err && h->dyn_host[4]) err = NL_ERR_CAPACITY;
+  }
   h->built = err == NL_OK;
   if (err) return fail(h, err);
   return NL_OK;
@@ -1081,11 +1090,13 @@ int make_list_slab_part(nl_handle_t h, const void* q_dev, int32_t q_stride, cons
 
 int nl_make_list_slab(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
                       int32_t n, int32_t z_lo, int32_t z_hi, void* stream, int sync) {
+  if (h) h->b_dyn = nullptr, h->dyn_host = nullptr;
   return make_list_slab_part(h, q_dev, q_stride, gid_dev, n_rows, n, 0, z_lo, z_hi, stream, sync, PART_ALL);
 }
 
 int nl_make_list_slab_begin(nl_handle_t h, const void* q_dev, int32_t q_stride, const int32_t* gid_dev, int32_t n_rows,
                             int32_t n, int32_t n_ghost_lo, int32_t z_lo, int32_t z_hi, void* stream) {
+  if (h) h->b_dyn = nullptr, h->dyn_host = nullptr;
   return make_list_slab_part(h, q_dev, q_stride, gid_dev, n_rows, n, n_ghost_lo, z_lo, z_hi, stream, 0, PART_BEGIN);
 }
 

@@ -416,6 +416,9 @@ struct BinPhase {
   int32_t base_lo, base_hi;
   int32_t cells_row0, cells_n0, cells_row1;  // k_bin_cells: block b < cells_n0 -> row cells_row0 + b, else cells_row1 + b - cells_n0
   int32_t check_lo;            // >= 0: this pass must hold exactly that many particles in rows < split_row (ST_DOMAIN)
+  const int32_t* dyn;          // != nullptr (nl_make_list_distributed, whole-build passes only): the pass ends at particle
+                               // g.n_rows + dyn[0] + dyn[1] -- the ghost counts of this build, known on the device only (the
+                               // host sizes the launch for i_end, an upper bound, and never waits for them)
 };
 
 template <typename T>
@@ -427,7 +430,8 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_rows(const T* __restrict__ 
   const int tid = threadIdx.x;
   for (int32_t r = tid; r < nrows; r += BIN_THREADS) hist[r] = 0;
   __syncthreads();
-  const int32_t beg = ph.i_beg + blockIdx.x * chunk, end = min(beg + chunk, ph.i_end);
+  const int32_t i_end = ph.dyn ? min(ph.i_end, g.n_rows + ph.dyn[0] + ph.dyn[1]) : ph.i_end;
+  const int32_t beg = ph.i_beg + blockIdx.x * chunk, end = min(beg + chunk, i_end);
   // BIN_UNROLL particles per thread and trip, all loads first: one memory round trip per trip instead of one per
   // particle (a chunk is 4 particles per thread).
   for (int32_t i0 = beg + tid; i0 < end; i0 += BIN_UNROLL * BIN_THREADS) {
@@ -504,7 +508,8 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
     if (blockIdx.x == 0 && tid == 0) row_start[nrows] = all + ph.base_hi;
   }
   __syncthreads();
-  const int32_t beg = ph.i_beg + blockIdx.x * chunk, end = min(beg + chunk, ph.i_end);
+  const int32_t i_end = ph.dyn ? min(ph.i_end, g.n_rows + ph.dyn[0] + ph.dyn[1]) : ph.i_end;
+  const int32_t beg = ph.i_beg + blockIdx.x * chunk, end = min(beg + chunk, i_end);
   const bool gid_in_w = gid == reinterpret_cast<const int32_t*>(1);  // NL_GID_IN_W: the id travels in the w component
   for (int32_t i0 = beg + tid; i0 < end; i0 += BIN_UNROLL * BIN_THREADS) {  // all loads of a trip first (see k_bin_rows)
     T x[BIN_UNROLL], y[BIN_UNROLL], z[BIN_UNROLL];

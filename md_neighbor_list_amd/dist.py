@@ -112,13 +112,23 @@ class DistributedNeighList:
         return n
 
     def build(self, sync=True):
-        """nl_make_list_distributed on the held buffer: pack, counts, halo, slab build -- all in the library."""
+        """nl_make_list_distributed on the held buffer: pack, halo messages, unpack, slab build -- all in the library, and
+        with sync=False without a single wait on the host (the ghost counts stay on the device: ``ghosts()``)."""
         nl = self.nl
         stream = torch.cuda.current_stream(nl.device).cuda_stream
         nl._q = self.q
         check(self._lib.nl_make_list_distributed(nl._h, self._comm, self.q.data_ptr(), self.q.shape[0], self.n_owned, stream,
                                                  1 if sync else 0), "nl_make_list_distributed")
+        nl._n_rows = self.n_owned
+        if sync:
+            self.ghosts()
+        else:
+            nl._n = self.n_owned + getattr(self, "n_ghost_lo", 0) + getattr(self, "n_ghost_hi", 0)
+
+    def ghosts(self):
+        """(ghosts from below, from above) of the last build; waits for it."""
         lo, hi = C.c_int32(), C.c_int32()
         check(self._lib.nl_distributed_ghosts(self._comm, C.byref(lo), C.byref(hi)))
         self.n_ghost_lo, self.n_ghost_hi = int(lo.value), int(hi.value)
-        nl._n, nl._n_rows = self.n_owned + self.n_ghost_lo + self.n_ghost_hi, self.n_owned
+        self.nl._n = self.n_owned + self.n_ghost_lo + self.n_ghost_hi
+        return self.n_ghost_lo, self.n_ghost_hi

@@ -116,16 +116,37 @@ def worker_cabi(rank, world, mode, q, box, rc, ret):
     dn = DistributedNeighList(nl, rank, world, transport="rccl" if mode == "cabi_rccl1" else "host")
     rng = np.random.default_rng(5)
     ghosts_seen = []
-    for rnd in range(2):
-        if rnd:  # everybody moves by up to 0.45 cells; coordinates stay inside the box
+    for rnd in range(3):
+        if rnd == 1:  # everybody moves by up to 0.45 cells; coordinates stay inside the box
             q = q.copy()
             q[:, :3] += rng.uniform(-1.5, 1.5, size=(n, 3)).astype(q.dtype)
             q[:, :3] = np.mod(q[:, :3], np.array(box, dtype=q.dtype))
             q[:, :3] = np.minimum(q[:, :3], np.nextafter(np.array(box, dtype=q.dtype), q.dtype.type(0)))
+        if rnd == 2:  # a ninth of the particles gathers in the two z layers at the first cut: those boundary layers grow
+            # beyond the capacity their messages were negotiated for (count + 25 % + 1024)
+            q = q.copy()
+            mz = int(box[2] / rc)
+            cut = (mz // world + (1 if mz % world else 0)) * (box[2] / mz)
+            k = n // 9
+            q[:k, 2] = (cut + rng.uniform(-0.95, 0.95, size=k) * (box[2] / mz)).astype(q.dtype)
         dn.scatter(torch.from_numpy(q).cuda(), box, rc)
-        for sync in (True, False):
+        for sync in ((True, False) if rnd < 2 else (False, True, False)):  # (the synchronous build also grows the pair list for the crowd)
             dn.build(sync=sync)
+            if rnd == 2 and world > 1 and sync is False and not ghosts_seen[-1][1:] == ("renegotiated",):
+                # the first asynchronous build after the crowd formed: its messages were too small, and it says so at
+                # its synchronisation; the next build negotiates new capacities
+                try:
+                    nl.synchronize()
+                    overflowed = False
+                except Exception as e:  # NL_ERR_CAPACITY
+                    overflowed = "capacity" in str(e).lower()
+                flags = [None] * world
+                dist.all_gather_object(flags, overflowed)
+                assert any(flags), "no rank saw a boundary layer outgrow its message"
+                ghosts_seen.append((ghosts_seen[-1][0], "renegotiated"))
+                continue
             nl.synchronize()
+            dn.ghosts()
             kp = nl.key_pointer().cpu().numpy()
             sl = nl.sorted_list().cpu().numpy()
             assert len(kp) == dn.n_owned + 1
@@ -141,10 +162,10 @@ def worker_cabi(rank, world, mode, q, box, rc, ret):
                 assert np.array_equal(got, want), rnd
         ghosts_seen.append((dn.n_ghost_lo, dn.n_ghost_hi))
     g2 = [None] * world
-    dist.all_gather_object(g2, ghosts_seen)
+    dist.all_gather_object(g2, [g for g in ghosts_seen if g[1:] != ("renegotiated",)])
     if rank == 0:
         if world > 1:
-            assert any(a[0] != a[1] for a in g2), g2  # the ghost counts did change between the two builds
+            assert any(a[0] != a[1] for a in g2), g2  # the ghost counts did change between the builds
         ret.put(("ok", 0, g2))
 
 
