@@ -191,10 +191,14 @@ def _stage_table(stages, info, n, p, vec_bytes, pos_bytes, full=False):
         "positions read; row-grouped copy written and read; sorted positions + row + id written")
     add("pair search COUNT" + (" keeping hit masks" if info["masks"] else ""), "count", (pos_bytes + 4) * n + 4 * n + masks,
         "sorted positions + rows read once, counts" + (f" and {192 * nb} B of hit masks per particle" if info["masks"] else "") + " written")
-    add("row scan (+ row offsets in cell order)", "row_scan", 4 * n + 4 * n + 4 * n, "counts read twice, key_pointer written")
+    add("row scan (k_scan_chained)", "row_scan", 4 * n + 4 * n, "counts read, key_pointer written")
     if info["masks"]:
-        add("expansion (k_row_base, " + ("k_fill_dense" if nb > 1 else "k_fill_masks") + ")", "fill", masks + 12 * n + 4 * n + 4 * p,
-            "hit masks, ids, row offsets read; the list written")
+        if nb > 1:
+            add("expansion (k_row_base, k_fill_dense)", "fill", masks + 12 * n + 4 * n + 4 * p,
+                "hit masks, ids, row offsets read; the list written")
+        else:
+            add("expansion (" + ("k_fill_rows" if info.get("fine_rows") else "k_fill_masks") + ")", "fill", masks + 12 * n + 4 * p,
+                "hit masks, ids, row ids and their list offsets read; the list written")
     else:
         add("pair search FILL", "fill", (pos_bytes + 4) * n + 4 * n + 4 * p, "sorted positions + offsets read; the list written")
     return rows

@@ -93,7 +93,8 @@ struct nl_handle_s {
                                          // launch = fewer resident workgroups per CU (occupancy experiments)
   int32_t* cell_count = nullptr;  // [ncell] followed by the status word
   int32_t* cell_start = nullptr;  // [ncell + 1]
-  int64_t* block_sum = nullptr;
+  uint64_t* scan_look = nullptr;  // k_scan_chained: [scan_blocks] entries + the two counters; all zero between launches
+  int32_t scan_blocks = 0;
   int64_t* totals = nullptr;  // [0] = particles (cell scan), [1] = pairs (row scan)
   uint32_t* status = nullptr;
   int32_t* list = nullptr;
@@ -227,15 +228,9 @@ int launch_scan(nl_handle_t h, const int32_t* in, int64_t n, OFF* out, int64_t* 
     return NL_OK;
   }
   const int32_t nb = (int32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-  hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum);
-  if (nb <= SCAN_FUSED_MAX) {  // every block of the down-sweep adds up the block sums before it: one launch less
-    hipLaunchKernelGGL((k_scan_down<true, OFF>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
-                       total_split);
-    return NL_OK;
-  }
-  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, s, h->block_sum, nb, total);
-  hipLaunchKernelGGL((k_scan_down<false, OFF>), dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->block_sum, total, out, h->status,
-                     total_split);
+  if (nb > h->scan_blocks) return fail(h, NL_ERR_ARG);  // (sized for max(n_max, cells) in nl_reserve)
+  hipLaunchKernelGGL(k_scan_chained<OFF>, dim3(nb), dim3(SCAN_THREADS), 0, s, in, n, h->scan_look, h->scan_blocks, total, out,
+                     h->status, total_split);
   return NL_OK;
 }
 
@@ -262,6 +257,7 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.progress = h->progress;
   a.key_pointer = h->key_pointer;
   a.wide = h->b_wide ? 1 : 0;
+  a.n_rows = h->n_rows;
   a.list = h->list;
   a.total = h->totals + 1;
   a.capacity = h->capacity;
@@ -312,29 +308,22 @@ template <int V, bool FULL> void launch_rows(nl_handle_t h, int mode, int32_t nc
     hipLaunchKernelGGL((k_rows_overflow<MODE_COUNT, FULL, int32_t>), dim3(over_grid), dim3(ROWS_WAVES * WAVE), 0, s, a);
     return;
   }
-  const int32_t nbp = (h->n + 255) / 256;
   if (h->b_wide) {
-    if (h->n > 0)
-      hipLaunchKernelGGL(k_row_base<int64_t>, dim3(nbp), dim3(256), 0, s, static_cast<const int64_t*>(h->key_pointer), h->sorted_row,
-                         h->n_rows, h->n, static_cast<int64_t*>(h->base_sorted));
-    hipLaunchKernelGGL((k_fill_rows<V, FULL, int64_t>), dim3(ncells_i), dim3(ROWS_FW * WAVE), 0, s, a, static_cast<const int64_t*>(h->base_sorted));
+    hipLaunchKernelGGL((k_fill_rows<V, FULL, int64_t>), dim3(ncells_i), dim3(ROWS_FW * WAVE), 0, s, a);
     hipLaunchKernelGGL((k_rows_overflow<MODE_FILL, FULL, int64_t>), dim3(over_grid), dim3(ROWS_WAVES * WAVE), 0, s, a);
   } else {
-    if (h->n > 0)
-      hipLaunchKernelGGL(k_row_base<int32_t>, dim3(nbp), dim3(256), 0, s, static_cast<const int32_t*>(h->key_pointer), h->sorted_row,
-                         h->n_rows, h->n, static_cast<int32_t*>(h->base_sorted));
-    hipLaunchKernelGGL((k_fill_rows<V, FULL, int32_t>), dim3(ncells_i), dim3(ROWS_FW * WAVE), 0, s, a, static_cast<const int32_t*>(h->base_sorted));
+    hipLaunchKernelGGL((k_fill_rows<V, FULL, int32_t>), dim3(ncells_i), dim3(ROWS_FW * WAVE), 0, s, a);
     hipLaunchKernelGGL((k_rows_overflow<MODE_FILL, FULL, int32_t>), dim3(over_grid), dim3(ROWS_WAVES * WAVE), 0, s, a);
   }
 }
 
 // FULL = the list keeps both directions of every pair (the reference GPU class's contract).
 template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(nl_handle_t h, const SweepArgs<T>& a, int32_t ncells_i, hipStream_t s) {
-  const int32_t nbp = (h->n + 255) / 256;
-  if (h->n > 0)
-    hipLaunchKernelGGL(k_row_base<OFF>, dim3(nbp), dim3(256), 0, s, static_cast<const OFF*>(h->key_pointer), h->sorted_row,
-                       h->n_rows, h->n, static_cast<OFF*>(h->base_sorted));
-  if (h->b_mask_nb > 1) {  // dense build: mask rows per (slot, LDS batch)
+  if (h->b_mask_nb > 1) {  // dense build: mask rows per (slot, LDS batch); list offsets gathered into cell order first
+    const int32_t nbp = (h->n + 255) / 256;
+    if (h->n > 0)
+      hipLaunchKernelGGL(k_row_base<OFF>, dim3(nbp), dim3(256), 0, s, static_cast<const OFF*>(h->key_pointer), h->sorted_row,
+                         h->n_rows, h->n, static_cast<OFF*>(h->base_sorted));
     hipLaunchKernelGGL((k_fill_dense<T, FULL, PBC, OFF>), dim3(ncells_i), dim3(FD_WAVES * WAVE), 0, s, a,
                        static_cast<const OFF*>(h->base_sorted));
     return;
@@ -342,11 +331,9 @@ template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(
   // rows a wave loads up front: 24, or 12 where cells hold ~20 particles or fewer (a wave then has ~10 rows)
   const bool few_rows = (double)h->n <= 21.0 * (double)std::max<int64_t>(1, h->ncell_local);
   if (few_rows)
-    hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF, 12>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
-                       static_cast<const OFF*>(h->base_sorted));
+    hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF, 12>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a);
   else
-    hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF, 24>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a,
-                       static_cast<const OFF*>(h->base_sorted));
+    hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF, 24>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a);
   // cells without masks (a stream of several LDS batches among one-batch neighbours): a second distance search
   hipLaunchKernelGGL((k_fill_list<T, FULL, PBC>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, a);
 }
@@ -871,7 +858,7 @@ int nl_destroy(nl_handle_t h) {
   (void)hipSetDevice(h->device);
   if (h->pending && h->last_stream) (void)hipStreamSynchronize(h->last_stream);
   void* bufs[] = {h->rank, h->sorted, h->sorted_row, h->sorted_gid, h->count, h->key_pointer, h->kp_alt, h->progress, h->base_sorted, h->row_start, h->blk_base, h->tmp_pos, h->tmp_row, h->masks, h->full27_list, h->resort_buf, h->dbg_buf, h->cell_count,
-                  h->cell_start, h->block_sum, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
+                  h->cell_start, h->scan_look, h->totals, h->list, h->t_list, h->t_count, h->t_cursor};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (h->host) (void)hipHostFree(h->host);
@@ -897,7 +884,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   int rc;
   if ((rc = dev_alloc(h, &h->rank, 4 * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->sorted, pos_bytes * (n + 16)))) return rc;
-  if ((rc = dev_alloc(h, &h->sorted_row, 4 * (n + 16)))) return rc;
+  if ((rc = dev_alloc(h, &h->sorted_row, 4 * (n + 64)))) return rc;  // (+64: k_fill_masks reads whole row batches)
   if ((rc = dev_alloc(h, &h->sorted_gid, 4 * (n + 16)))) return rc;
   if ((rc = dev_alloc(h, &h->count, 4 * (n + 32)))) return rc;
   if ((rc = dev_alloc(h, &h->key_pointer, 8 * (n + 32)))) return rc;  // int32 or int64 offsets (b_wide)
@@ -905,7 +892,7 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   h->kp_alt_valid = false;
   if (h->resort_buf) (void)hipFree(h->resort_buf), h->resort_buf = nullptr;
   if ((rc = dev_alloc(h, &h->progress, 4 * (n + 16)))) return rc;
-  if ((rc = dev_alloc(h, &h->base_sorted, 8 * (n + 64)))) return rc;  // (+64: k_fill_masks reads whole row batches)
+  if ((rc = dev_alloc(h, &h->base_sorted, 8 * (n + 64)))) return rc;  // (dense builds only: k_fill_dense)
   {
     const size_t nrows = (size_t)h->m[1] * h->m[2];
     // chunk per block: 4096 particles, 8192 from half a million on (cfg 2: binning 60.7 -> 55.9 us, cfg 3 64.7 -> 58.0;
@@ -932,7 +919,9 @@ int nl_initialize(nl_handle_t h, int32_t n_max) {
   h->row_count = h->cell_count + h->ncell + 32;
   if ((rc = dev_alloc(h, &h->cell_start, 4 * (4 * (size_t)h->ncell + 32)))) return rc;  // (cell_start, or the fine-row table: 4 M + 1)
   const size_t nblk = std::max<size_t>(n, (size_t)h->ncell) / SCAN_BLOCK + 2;
-  if ((rc = dev_alloc(h, &h->block_sum, 8 * nblk))) return rc;
+  if ((rc = dev_alloc(h, &h->scan_look, 8 * (nblk + 1)))) return rc;
+  HIPCHK(h, hipMemset(h->scan_look, 0, 8 * (nblk + 1)));
+  h->scan_blocks = (int32_t)nblk;
   if ((rc = dev_alloc(h, &h->totals, 8 * 4))) return rc;
   h->status = reinterpret_cast<uint32_t*>(h->cell_count + h->ncell);  // cleared by the same memset as the histogram
   HIPCHK(h, hipMemset(h->totals, 0, 32));

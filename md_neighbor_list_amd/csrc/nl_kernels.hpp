@@ -179,7 +179,6 @@ __global__ void __launch_bounds__(256) k_reorder(const T* __restrict__ q, int32_
 // ---------------------------------------------------------------------------------------------- scans
 // Exclusive scan of int32 counts (a4: thrust reduce_by_key + inclusive_scan neighlist_gpu.hpp:153-175 /
 // MakeNextDest neighlist_cpu.hpp:146-152; a9: MakeNeighListForEachPtcl neighlist_cpu.hpp:361-367).
-// Three small kernels: per-block sums, a one-block scan of those sums (64-bit), per-block scan + offset.
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;  // per thread, loaded as 4 x int4
 constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
@@ -237,76 +236,42 @@ __device__ __forceinline__ void load_items(const int32_t* __restrict__ in, int64
   }
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_reduce(const int32_t* __restrict__ in, int64_t n,
-                                                               int64_t* __restrict__ block_sum) {
-  __shared__ int32_t wsum[SCAN_THREADS / WAVE];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  int32_t v[SCAN_ITEMS];
-  load_items(in, n, (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_ITEMS, v);
-  int32_t s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) s += v[k];
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, WAVE);
-  if (lane == 0) wsum[w] = s;
-  __syncthreads();
-  if (tid == 0) {
-    int64_t t = 0;
-    for (int k = 0; k < SCAN_THREADS / WAVE; k++) t += wsum[k];
-    block_sum[blockIdx.x] = t;
-  }
-}
-
-// One block: exclusive scan of nb block sums in place; the grand total goes to total[0].
-__global__ void __launch_bounds__(1024) k_scan_spine(int64_t* __restrict__ block_sum, int32_t nb,
-                                                      int64_t* __restrict__ total) {
-  __shared__ int64_t wsum[16];
-  __shared__ int64_t carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int32_t base = 0; base < nb; base += 1024) {
-    const int32_t i = base + tid;
-    const int64_t x = i < nb ? block_sum[i] : 0;
-    int64_t inc = wave_incl_scan64(x, lane);
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    int64_t woff = 0;
-    for (int k = 0; k < w; k++) woff += wsum[k];
-    const int64_t carry = carry_s;
-    if (i < nb) block_sum[i] = carry + woff + inc - x;
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + woff + inc;
-    __syncthreads();
-  }
-  if (tid == 0) total[0] = carry_s;
-}
-
 // out[i] = exclusive prefix; out[n] = total.  OFF = int32_t (the reference's key_pointer type, neighlist_cpu.hpp:15,29):
 // flags ST_INDEX_OVERFLOW when the total exceeds INT32_MAX; OFF = int64_t (wide builds: lists beyond 2^31 entries,
 // BASELINE config 4 on one device) never overflows.
-// FUSED (up to SCAN_FUSED_MAX blocks): block_off holds the RAW block sums of k_scan_reduce; every block adds up the
-// sums before it itself (<= 8 KiB of reads) and the last block publishes the grand total -- no spine launch.
-constexpr int SCAN_FUSED_MAX = 1024;
-template <bool FUSED, typename OFF>
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __restrict__ in, int64_t n,
-                                                             const int64_t* __restrict__ block_off,
-                                                             int64_t* __restrict__ total,
-                                                             OFF* __restrict__ out,
-                                                             uint32_t* __restrict__ status,
-                                                             uint32_t* __restrict__ total_split) {
+//
+// ONE launch (chained scan with look-back): a block takes its number from a ticket counter (so every block with a
+// smaller number is running or done), publishes the sum of its 4096 items in look[b] (flag 1), adds up the entries of
+// the blocks before it -- wave 0 reads 64 of them per step and stops at the nearest one that already holds an
+// inclusive prefix (flag 2) -- and publishes its own prefix.  look[] = flag << 62 | value; look[nb_max], [nb_max + 1]
+// hold the ticket and the count of blocks that are through with look[]: the last of those clears the entries and the
+// two counters, so the array is all zero again when the kernel ends (no memset per build, graph replays included).
+// Everything a block needs from another one is inside the 64-bit entry, so all accesses to look[] are RELAXED
+// device-scope atomics (they bypass the per-XCD L2).  Acquire / release here would write back and invalidate the
+// whole L2 of the XCD at every step: the first version did, and took 36 us for 256 blocks.
+constexpr uint64_t SCAN_FLAG_SUM = 1ull << 62, SCAN_FLAG_PREFIX = 2ull << 62, SCAN_VALUE = (1ull << 62) - 1;
+__device__ __forceinline__ uint64_t scan_look_load(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void scan_look_store(uint64_t* p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename OFF>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_chained(const int32_t* __restrict__ in, int64_t n,
+                                                                uint64_t* __restrict__ look, int32_t nb_max,
+                                                                int64_t* __restrict__ total,
+                                                                OFF* __restrict__ out,
+                                                                uint32_t* __restrict__ status,
+                                                                uint32_t* __restrict__ total_split) {
   __shared__ int32_t wsum[SCAN_THREADS / WAVE];
-  __shared__ int64_t osum[SCAN_THREADS / WAVE];
+  __shared__ int64_t before_s;
+  __shared__ int32_t block_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_ITEMS;
-  int64_t my_off = 0;
-  if (FUSED) {
-    int64_t t = 0;
-    for (int32_t k = tid; k < (int32_t)blockIdx.x; k += SCAN_THREADS) t += block_off[k];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d, WAVE);
-    if (lane == 0) osum[w] = t;
-  }
+  uint32_t* counters = reinterpret_cast<uint32_t*>(look + nb_max);
+  if (tid == 0) block_s = (int32_t)__hip_atomic_fetch_add(&counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int32_t b = block_s, nb = (int32_t)gridDim.x;
+  const int64_t base = (int64_t)b * SCAN_BLOCK + (int64_t)tid * SCAN_ITEMS;
   int32_t v[SCAN_ITEMS];
   load_items(in, n, base, v);
   int32_t s = 0;
@@ -315,15 +280,39 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
   const int32_t inc = wave_incl_scan(s, lane);
   if (lane == 63) wsum[w] = inc;
   __syncthreads();
-  int32_t woff = 0;
-  for (int k = 0; k < w; k++) woff += wsum[k];
-  if (FUSED) {
+  int32_t woff = 0, sum = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_THREADS / WAVE; k++) my_off += osum[k];
-  } else {
-    my_off = block_off[blockIdx.x];
+  for (int k = 0; k < SCAN_THREADS / WAVE; k++) {
+    if (k < w) woff += wsum[k];
+    sum += wsum[k];
   }
-  OFF run = (OFF)my_off + (OFF)(woff + inc - s);
+  if (w == 0) {
+    if (lane == 0 && b > 0) scan_look_store(&look[b], SCAN_FLAG_SUM | (uint64_t)sum);
+    int64_t before = 0;
+    for (int32_t hi = b - 1; hi >= 0; hi -= WAVE) {  // wave-uniform
+      const int32_t idx = hi - lane;
+      uint64_t e = SCAN_FLAG_PREFIX;  // (in front of block 0: prefix 0)
+      for (;;) {
+        if (idx >= 0) e = scan_look_load(&look[idx]);
+        if (__ballot((e >> 62) == 0) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const uint64_t has_prefix = __ballot((e >> 62) == 2);  // never zero in the last step (idx < 0 lanes, or block 0)
+      const int first = has_prefix ? __builtin_ctzll(has_prefix) : WAVE;
+      int64_t part = lane <= first ? (int64_t)(e & SCAN_VALUE) : 0;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, WAVE);
+      before += part;
+      if (has_prefix) break;
+    }
+    if (lane == 0) {
+      scan_look_store(&look[b], SCAN_FLAG_PREFIX | (uint64_t)(before + sum));
+      before_s = before;
+    }
+  }
+  __syncthreads();
+  const int64_t before = before_s;
+  OFF run = (OFF)before + (OFF)(woff + inc - s);
   if (sizeof(OFF) == 4 && base + SCAN_ITEMS <= n) {
     int4* p = reinterpret_cast<int4*>(out + base);
 #pragma unroll
@@ -342,14 +331,27 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_down(const int32_t* __res
       run += v[k];
     }
   }
-  if (FUSED ? (blockIdx.x == gridDim.x - 1 && tid == 0) : (blockIdx.x == 0 && tid == 0)) {
-    const int64_t t = FUSED ? my_off + block_off[blockIdx.x] : total[0];
-    if (FUSED) total[0] = t;
+  if (b == nb - 1 && tid == 0) {
+    const int64_t t = before + sum;
+    total[0] = t;
     out[n] = (OFF)t;
     if (sizeof(OFF) == 4 && t > 2147483647LL) atomicOr(status, ST_INDEX_OVERFLOW);
     if (total_split) {  // the grand total next to the status word: one small device->host copy per build
       total_split[0] = (uint32_t)t;
       total_split[1] = (uint32_t)((unsigned long long)t >> 32);
+    }
+  }
+  // through with look[] (own prefix published before this, by the barrier above): the last block to get here clears it
+  if (tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);  // this thread's store to look[b] has been acknowledged before the count goes up
+    block_s = (int32_t)__hip_atomic_fetch_add(&counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (block_s == nb - 1) {
+    for (int32_t k = tid; k < nb; k += SCAN_THREADS) scan_look_store(&look[k], 0);
+    if (tid == 0) {
+      __hip_atomic_store(&counters[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -713,6 +715,7 @@ template <typename T> struct SweepArgs {
   int32_t* __restrict__ progress; // [n_rows] scratch, only touched when a stencil needs more than one LDS batch
   const void* __restrict__ key_pointer;  // [n_rows + 1] int32 offsets, or int64 when `wide`
   int32_t wide;                   // this build's list may exceed 2^31 entries: key_pointer / base_sorted hold int64
+  int32_t n_rows;                 // owned particles (rows of the list); slots of ghosts carry row ids >= n_rows
   int32_t* __restrict__ list;
   const int64_t* __restrict__ total;
   int64_t capacity;
@@ -1536,7 +1539,7 @@ constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 work
 
 template <typename T, bool FULL = false, bool PBC = false, typename OFF = int32_t, int RB = 24>
 __global__ void __launch_bounds__(EXPAND_WAVES* WAVE, (sizeof(OFF) == 8 ? 4 : sizeof(T) == 4 ? (FULL ? 7 : 8) : 4)) __attribute__((amdgpu_num_sgpr(80)))
-k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
+k_fill_masks(SweepArgs<T> a) {
   constexpr int CAP = SweepCfg<T>::CAP;
   constexpr int EW = EXPAND_WAVES;
   constexpr int EXPAND_RMAX = EXPAND_RMAX_OF<FULL>;
@@ -1582,8 +1585,15 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
   const int32_t per_wave = (c.ni + EW - 1) / EW;
   const int32_t r_beg = min(wave * per_wave, c.ni), r_end = min(r_beg + per_wave, c.ni);
   uint32_t w[RB];
-  OFF base[RB];
+  OFF base_l;  // lane u: list offset of row r0 + u
   auto load_rows = [&](int32_t r0) {
+    {
+      // key_pointer[sorted_row[slot]] of the batch's rows, a lane per row: two dependent loads per batch in the shadow
+      // of the mask loads (round 2 had a gather kernel in front, k_row_base: a launch and 8 MB of traffic per build).
+      // Slots past the cell's last row belong to other cells, ghosts or the padding: any row id is good enough there.
+      const int32_t srow = a.sorted_row[c.ibeg + r0 + min(lane, RB - 1)];
+      base_l = static_cast<const OFF*>(a.key_pointer)[min((uint32_t)srow, (uint32_t)a.n_rows)];
+    }
 #if NL_FILL_NOCLAMP
     // Consecutive slots are consecutive 192-byte rows: ONE 64-bit base address per batch, the rows at immediate offsets
     // from it.  Rows past the cell's last one are read as well (the next cells' rows, or the 64 rows of padding behind
@@ -1591,12 +1601,10 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
     // instructions per row on 64-bit address arithmetic: 400 per wave.)
     const size_t slot0 = (size_t)(c.ibeg + r0);
     const char* const mrow0 = reinterpret_cast<const char*>(a.masks) + slot0 * MASK_ROW_BYTES;  // (one mask row per slot here)
-    const OFF* const brow0 = base_sorted + slot0;
 #pragma unroll
     for (int u = 0; u < RB; u++) {
       const char* const row = mrow0 + u * MASK_ROW_BYTES;
       w[u] = (uint32_t)reinterpret_cast<const uint16_t*>(row)[lane] | (uint32_t)reinterpret_cast<const uint8_t*>(row + 2 * WAVE)[lane] << 16;
-      base[u] = brow0[u];  // (k_row_base: one gather kernel is cheaper than two dependent loads here)
     }
 #else
 #pragma unroll
@@ -1610,9 +1618,14 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
 #else
       w[u] = mask_load(a.masks, (size_t)slot, lane);
 #endif
-      base[u] = base_sorted[slot];
     }
 #endif
+  };
+  auto base = [&](int u) -> OFF {  // u: compile-time constant after unrolling
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)base_l, u);
+    if constexpr (sizeof(OFF) == 4) return (OFF)lo;
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)((uint64_t)base_l >> 32), u);
+    return (OFF)((uint64_t)hi << 32 | lo);
   };
   load_rows(r_beg);  // issued before the id staging: independent of the segment table
   if (a.dbg & 32) return;  // diagnostics: setup + loads only
@@ -1700,7 +1713,7 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
           for (int q = 0; q < 4; q++) val[q] = cw[q * EXPAND_RMAX + min(e, EXPAND_RMAX - 1)];
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            if (e < nrow[q]) a.list[(size_t)base[u0 + q] + e] = val[q];
+            if (e < nrow[q]) a.list[(size_t)base(u0 + q) + e] = val[q];
         }
         __builtin_amdgcn_wave_barrier();
 #if NL_STAMP_FILL
@@ -1720,7 +1733,7 @@ k_fill_masks(SweepArgs<T> a, const OFF* __restrict__ base_sorted) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           if (on[q]) {
-            a.list[(size_t)base[u0 + q] + ptr[q]] = val[q];
+            a.list[(size_t)base(u0 + q) + ptr[q]] = val[q];
             ptr[q]++;
             word[q] &= word[q] - 1;
           }

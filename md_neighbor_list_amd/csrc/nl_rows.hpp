@@ -517,7 +517,8 @@ template <typename OFF, typename word_t, int RB> struct FillRows {
   RowsQ rq;
   int32_t l1, l2, l3, ql0, ql1, ql2, ql3;  // first particle of share 1, 2, 3 of the COUNT sweep; first quarter of the four shares
   const char* masks;
-  const OFF* base_sorted;
+  const OFF* key_pointer;
+  const int32_t* sorted_row;
   // issues the loads of rows r0 .. r0 + RB - 1: list offsets into base_l, hit words by LDS-DMA into `rows`
   __device__ __forceinline__ void issue(int32_t r0, int lane, int32_t off_l, int32_t& s1_l, OFF& base_l, char* rows) const {
     constexpr int ROWB = WAVE * (int)sizeof(word_t), LPR = ROWB / 16, RPP = WAVE / LPR;  // bytes per row, lanes / rows per DMA piece
@@ -528,7 +529,7 @@ template <typename OFF, typename word_t, int RB> struct FillRows {
     const int32_t qlo = ql0 + (seq >= l1 ? ql1 - ql0 : 0) + (seq >= l2 ? ql2 - ql1 : 0) + (seq >= l3 ? ql3 - ql2 : 0);
     const int32_t bq = rows_quarter_of(rq, seq) - qlo >= 2 ? qlo + 2 : qlo;
     s1_l = __shfl(off_l, 3 * bq, WAVE);
-    base_l = base_sorted[slot_l];
+    base_l = key_pointer[sorted_row[slot_l]];  // (two dependent loads per batch, in the shadow of the DMA below: no gather kernel in front)
     const int32_t nb = min(n - r0, RB);
 #pragma unroll
     for (int pc = 0; pc < (RB + RPP - 1) / RPP; pc++) {
@@ -545,7 +546,7 @@ template <typename OFF, typename word_t, int RB> struct FillRows {
 
 template <int V, bool FULL, typename OFF>
 __global__ void __launch_bounds__(ROWS_FW* WAVE, (sizeof(OFF) == 8 && RowsCfg<V>::WF > 6 ? 6 : RowsCfg<V>::WF)) __attribute__((amdgpu_num_sgpr(96)))
-k_fill_rows(RowsArgs a, const OFF* __restrict__ base_sorted) {
+k_fill_rows(RowsArgs a) {
   typedef RowsCfg<V> Cfg;
   typedef typename Cfg::word_t word_t;
   constexpr int CAP = Cfg::CAP, ROWB = WAVE * (int)sizeof(word_t), RB = ROWS_RBYTES / ROWB / 4 * 4;  // 20 rows of 16-bit words, 8 of 32-bit words
@@ -586,7 +587,7 @@ k_fill_rows(RowsArgs a, const OFF* __restrict__ base_sorted) {
     fr.l1 = s1.lo, fr.l2 = s2.lo, fr.l3 = s3.lo;
     fr.ql0 = s0.qlo, fr.ql1 = s1.qlo, fr.ql2 = s2.qlo, fr.ql3 = s3.qlo;
   }
-  fr.masks = static_cast<const char*>(a.masks), fr.base_sorted = base_sorted;
+  fr.masks = static_cast<const char*>(a.masks), fr.key_pointer = static_cast<const OFF*>(a.key_pointer), fr.sorted_row = a.sorted_row;
   const int32_t n = fr.n;  // rows of this wave
   int32_t s1_l = 0;
   OFF base_l = 0;
