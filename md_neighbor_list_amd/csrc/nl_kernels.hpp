@@ -783,36 +783,19 @@ struct ScreenCtx {
 template <typename T, bool SCREEN> struct TileOf { typedef Pos<T> type; };
 template <typename T> struct TileOf<T, true> { typedef PosS type; };
 
-#ifndef NL_VBITS
-#define NL_VBITS 1
-#endif
-#ifndef NL_VBITS_SPLIT
-#define NL_VBITS_SPLIT 1
-#endif
-#ifndef NL_STAGE_DMA
-#define NL_STAGE_DMA 1
-#endif
-#ifndef NL_PRIO  // wave priority outside the tile loop of the COUNT_MASKS sweeps (0: leave it alone)
-#define NL_PRIO 3
-#endif
-#ifndef NL_VBITS_SCREEN
-#define NL_VBITS_SCREEN 1
-#endif
-#ifndef NL_COUNT_WPE
-#define NL_COUNT_WPE 0
-#endif
-#ifndef NL_STAMP  // timing experiments only: per-phase wave cycles of the COUNT_MASKS sweep into dbg_buf[16..] (tools/count_phases.py)
+// Compile-time switches: timing instruments only (the kernel experiments of rounds 2 and 3 -- compare form against
+// sign-bit recording, split tile parts, register staging, priorities, clamped row addresses -- are settled and gone;
+// profiles/r02_count_sweep_investigation.txt has their A/B tables).
+#ifndef NL_STAMP  // per-phase wave cycles of the COUNT_MASKS sweeps into dbg_buf[16..] (tools/count_phases.py, tools/rows_phases.py)
 #define NL_STAMP 0
 #endif
-#ifndef NL_FILL_NOCLAMP
-#define NL_FILL_NOCLAMP 1
-#endif
-#ifndef NL_STAMP_FILL  // the same for k_fill_masks (tools/fill_phases.py); not together with NL_STAMP
+#ifndef NL_STAMP_FILL  // the same for the expansion kernels (tools/fill_phases.py); not together with NL_STAMP
 #define NL_STAMP_FILL 0
 #endif
-#ifndef NL_DIAG  // timing experiments only (wrong lists): 1 = no tile tests, 2 = no mask stores, 4 = no staging loads
+#ifndef NL_DIAG  // wrong lists, timing only: 1 = no tile tests, 2 = no mask stores, 4 = no staging loads
 #define NL_DIAG 0
 #endif
+constexpr int NL_PRIO = 3;  // wave priority outside the tile loop of the COUNT_MASKS sweeps
 // r2 of one staged fp32 particle against the GC i-particles: the reference's expression, every operation rounded on
 // its own.  (The squares of two tests through one v_pk_mul_f32 -- each half an IEEE multiply, same bits -- measured
 // 10 % slower: packed fp32 issues at half the rate of the plain forms on gfx950, profiles/r02_count_sweep_investigation.txt.)
@@ -858,11 +841,11 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   // instructions per test where two v_cmp (SGPR-pair results), an s_and, an add-with-carry, an s_bcnt1 and an s_add
   // were -- and no VALU -> SALU -> VALU dependency inside a tile.  The word collects NOT-accepted bits; inverted, and
   // the row counted from it (popcount + one DPP sum per i-particle), after the last tile.
-  constexpr bool VBITS_F32 = NL_VBITS && MODE == MODE_COUNT_MASKS && !SCREEN && sizeof(T) == 4 && (!FULL || NOSELF);
+  constexpr bool VBITS_F32 = MODE == MODE_COUNT_MASKS && !SCREEN && sizeof(T) == 4 && (!FULL || NOSELF);
   // The screened fp64 search in the same form: lo_in - r2f and r2f - hi_out carry "decided in range" / "decided out of
   // range" in their sign bits, the AND of the two over a tile's tests says whether any pair needs the exact expression
   // (ONE compare and branch per tile), and the exact answer then clears the bit the screen put into the word.
-  constexpr bool VBITS_SCREEN = NL_VBITS && NL_VBITS_SCREEN && MODE == MODE_COUNT_MASKS && SCREEN && (!FULL || NOSELF);
+  constexpr bool VBITS_SCREEN = MODE == MODE_COUNT_MASKS && SCREEN && (!FULL || NOSELF);
   constexpr bool VBITS = VBITS_F32 || VBITS_SCREEN;
   uint32_t gi1[GC];
 #pragma unroll
@@ -897,7 +880,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   // consumes a v_cmp result stalls the wave until the compare has left the VALU.
   auto test_tile = [&](const TileT& pj, int32_t tix) {
     if constexpr (VBITS_SCREEN) {
-      constexpr int HALF = NL_VBITS_SPLIT ? (GC + 1) / 2 : GC;
+      constexpr int HALF = (GC + 1) / 2;
       uint32_t uacc = 0;  // sign bit: some test of this tile is inside the band for this lane
 #pragma unroll
       for (int k = 0; k < GC; k++) {
@@ -943,7 +926,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
     if constexpr (VBITS_F32) {
       // The tests go in two parts with a scheduling barrier between them: left alone the compiler hoists the
       // subtractions of all GC tests to the top of the tile, 4 live registers per test, and the kernel loses a wave per SIMD.
-      constexpr int HALF = NL_VBITS_SPLIT ? (GC + 1) / 2 : GC;
+      constexpr int HALF = (GC + 1) / 2;
 #pragma unroll
       for (int k = 0; k < GC; k++) {
         if (k == HALF) __builtin_amdgcn_sched_barrier(0);
@@ -1048,9 +1031,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   const int32_t last = (ntiles - 1) * WAVE + lane;
   TileT pa = tile[lane], pb;
   int32_t t = (NL_DIAG & 1) ? ntiles : 0;
-#if NL_PRIO
   if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(0);  // the tile loop yields to waves that are setting up, staging, storing
-#endif
   for (; t + 1 < ntiles; t += 2) {  // both tests unconditional, so neither load can be sunk next to its use
     pb = tile[(t + 1) * WAVE + lane];
     test_tile(pa, t);
@@ -1058,9 +1039,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
     test_tile(pb, t + 1);
   }
   if (t < ntiles) test_tile(pa, t);
-#if NL_PRIO
   if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(NL_PRIO);
-#endif
   if constexpr (VBITS) {
     uint32_t w[GC], tot[GC];
     // the group's rows are mask_nb rows apart: one 64-bit row address, the others at 32-bit multiples of the stride
@@ -1248,7 +1227,7 @@ __device__ __forceinline__ void cell_search(const SweepArgs<T>& a, const CellCtx
     // (profiles/r02_count_staging_ab.txt) -- the staging phase was starved of issue slots, not waiting for memory
     // (DESIGN.md section 5); with s_setprio around the tile loop and 16-byte DMA it is 2 300 cycles of a wave's 36 000.
     float rmax = 0.f;  // SCREEN: largest L1 norm of the relative coordinates this thread stages
-    constexpr bool DMA = NL_STAGE_DMA && sizeof(T) == 4 && !PBC && !SCREEN && MODE == MODE_COUNT_MASKS;
+    constexpr bool DMA = sizeof(T) == 4 && !PBC && !SCREEN && MODE == MODE_COUNT_MASKS;
     for (int32_t sg = wave; sg < NSEG; sg += NW) {
       const int32_t len = __builtin_amdgcn_readlane(c.seg_len, sg);
       if (len == 0) continue;
@@ -1465,9 +1444,7 @@ __device__ __forceinline__ void sweep_cell(const SweepArgs<T>& a) {
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   CellCtx c;
-#if NL_PRIO
   if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(NL_PRIO);
-#endif
 #if NL_STAMP
   const uint64_t t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -1506,9 +1483,6 @@ k_sweep_count_f32(SweepArgs<float> a) {
 }
 template <bool FULL = false, bool PBC = false>
 __global__ void __launch_bounds__(SWEEP_WAVES* WAVE) __attribute__((amdgpu_num_sgpr(80)))
-#if NL_COUNT_WPE
-__attribute__((amdgpu_waves_per_eu(NL_COUNT_WPE, NL_COUNT_WPE)))
-#endif
 k_sweep_count_masks_f32(SweepArgs<float> a) {
   sweep_cell<float, MODE_COUNT_MASKS, FULL, PBC>(a);
 }
@@ -1594,7 +1568,6 @@ k_fill_masks(SweepArgs<T> a) {
       const int32_t srow = a.sorted_row[c.ibeg + r0 + min(lane, RB - 1)];
       base_l = static_cast<const OFF*>(a.key_pointer)[min((uint32_t)srow, (uint32_t)a.n_rows)];
     }
-#if NL_FILL_NOCLAMP
     // Consecutive slots are consecutive 192-byte rows: ONE 64-bit base address per batch, the rows at immediate offsets
     // from it.  Rows past the cell's last one are read as well (the next cells' rows, or the 64 rows of padding behind
     // the last slot) and ignored.  (With `slot = ibeg + min(r0 + u, ni - 1)` per row the compiler spent 17 scalar
@@ -1606,20 +1579,6 @@ k_fill_masks(SweepArgs<T> a) {
       const char* const row = mrow0 + u * MASK_ROW_BYTES;
       w[u] = (uint32_t)reinterpret_cast<const uint16_t*>(row)[lane] | (uint32_t)reinterpret_cast<const uint8_t*>(row + 2 * WAVE)[lane] << 16;
     }
-#else
-#pragma unroll
-    for (int u = 0; u < RB; u++) {
-      const int32_t slot = c.ibeg + min(r0 + u, c.ni - 1);
-#if NL_DIAG & 8  // timing experiment: no mask loads (one bit per lane instead: 64 entries per row)
-      {  // ~1.06 random bits of 17 per lane: the bit loops see the real distribution
-        uint32_t h1 = (uint32_t)(slot * 64 + lane) * 2654435761u, h2 = h1 * 2246822519u + 374761393u;
-        w[u] = (h1 >> 3) & (h1 >> 15) & (h2 >> 2) & (h2 >> 14) & 0x1FFFFu;
-      }
-#else
-      w[u] = mask_load(a.masks, (size_t)slot, lane);
-#endif
-    }
-#endif
   };
   auto base = [&](int u) -> OFF {  // u: compile-time constant after unrolling
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)base_l, u);

@@ -108,9 +108,7 @@ __global__ void __launch_bounds__(SWEEP_WAVES* WAVE, 8) __attribute__((amdgpu_nu
   constexpr int CAP = SweepCfg<float>::CAP, NW = SWEEP_WAVES;
   __shared__ __attribute__((aligned(32))) Pos<float> buf[CAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#if NL_PRIO
   __builtin_amdgcn_s_setprio(NL_PRIO);  // everything but the tile loop of search_group
-#endif
   CellCtx c;
   if (!cell_setup(a, lane, c)) return;
   if (c.total_j > CAP) {  // (rare) several LDS batches: k_sweep_list_f32

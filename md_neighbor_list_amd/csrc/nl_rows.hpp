@@ -238,7 +238,7 @@ template <int V> __device__ __forceinline__ bool rows_fits(const RowsCtx& c, con
 // The hit words of a row in memory: 64 words, word l = lane l's.  16-bit words are stored two to a dword by the even
 // lanes (the odd lane's word comes over by DPP): sub-dword vector stores are served at a fraction of the dword rate --
 // with global_store_short the COUNT sweep took 0.295 ms at BASELINE config 2, 0.115 ms without its stores
-// (profiles/r03_store_width.txt) -- and the expansion reads the dword back in both lanes.
+// (profiles/r03_fine_rows_investigation.txt) -- and the expansion reads the dword back in both lanes.
 template <typename word_t> __device__ __forceinline__ void rows_store_word(void* masks, int32_t slot, int lane, uint32_t w) {
   if constexpr (sizeof(word_t) == 2) {
     const uint32_t odd = (uint32_t)__builtin_amdgcn_update_dpp(0, (int32_t)w, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Soak: many seeded random problems (all sweep variants, both binning paths, both dtypes, both offset widths, half and
-full lists, open box and minimum image, uniform and clustered particles -- dense cells among sparse ones exercise the
-re-search paths, the dense-mask pipeline and the half-shell variant's 27-cell fall-back) against the oracle.
+"""Soak: many seeded random problems (both sweep variants, the fine-row search forced / allowed / off, both binning
+paths, both dtypes, both offset widths, half and full lists, open box and minimum image, uniform and clustered particles
+-- dense cells among sparse ones exercise the hand-over lists, the dense-mask pipeline and the fine-row overflow
+kernel) against the oracle.
 usage: tools/soak_parity.py [cases] [seed]"""
 import os
 import sys
@@ -22,6 +23,10 @@ for case in range(cases):
     os.environ["NL_SWEEP_VARIANT"] = os.environ.get("SOAK_VARIANT") or str(rng.choice([1, 3, 3]))
     os.environ["NL_OFFSET_WIDTH"] = str(rng.choice([0, 0, 64]))
     os.environ["NL_BINNING"] = str(rng.integers(0, 2))
+    rows = int(rng.choice([-1, -1, 0, 4, 4, 1, 2, 3]))  # -1: the library's own choice
+    os.environ.pop("NL_ROWS", None)
+    if rows >= 0:
+        os.environ["NL_ROWS"] = str(rows)
     rc = float(rng.uniform(0.5, 5.0))
     mesh = rng.integers(3, 14, size=3)
     box = tuple(float(m * rc * rng.uniform(1.0, 1.3)) for m in mesh)
@@ -66,7 +71,7 @@ for case in range(cases):
         if not ok:
             bad += 1
             print(f"MISMATCH case {case} rep {rep}: n={n} box={box} rc={rc} dtype={dtype.__name__} full={full} "
-                  f"pbc={pbc} variant={os.environ['NL_SWEEP_VARIANT']} width={os.environ['NL_OFFSET_WIDTH']} binning={os.environ['NL_BINNING']} info={nl.build_info()}", flush=True)
+                  f"pbc={pbc} variant={os.environ['NL_SWEEP_VARIANT']} width={os.environ['NL_OFFSET_WIDTH']} binning={os.environ['NL_BINNING']} rows={rows} info={nl.build_info()}", flush=True)
     if case % 50 == 49:
         print(f"{case + 1} cases, {bad} mismatches", flush=True)
 print(f"soak done: {cases} cases, {bad} mismatches")
