@@ -276,23 +276,39 @@ def main():
         nl.Initialize(n_total)
         step = lambda: nl.MakeNeighList(qd, n_total, sync=False)  # noqa: E731
         st = None
-    elif args.dist == "cabi":
-        from md_neighbor_list_amd.dist import DistributedNeighList
-
-        dn = DistributedNeighList(nl, rank, world, transport="host" if rehearsal else "rccl")
-        nl.Initialize(int(n_total / world * 1.6) + 65536)
-        n_own = dn.scatter(torch.from_numpy(q).to(dev), box, rc)
-        per = density * (2.0 / 3.0) * np.pi * rc**3
-        nl.set_capacity(int(n_own * per * 1.3) + 64 * n_own + 4096)
-        step = lambda: dn.build(sync=False)  # noqa: E731
-        st = None
     else:
-        st = slab.setup(torch.from_numpy(q).to(dev), None, box, rc, rank, world)
-        nl.Initialize(st.q_all.shape[0])
-        # the default capacity estimate uses the global density with the local count: size it for the slab
+        dn = None
         per = density * (2.0 / 3.0) * np.pi * rc**3
-        nl.set_capacity(int(st.n_rows * per * 1.3) + 64 * st.n_rows + 4096)
-        step = lambda: slab.build(nl, st, sync=False)  # noqa: E731
+        if args.dist == "cabi":
+            from md_neighbor_list_amd.dist import DistributedNeighList
+
+            # If the library's communicator cannot be set up or its first (synchronous) build fails on every rank alike
+            # -- RCCL not loadable, an API error -- all ranks fall back to the torch.distributed exchange together and
+            # the line says so.  (An error on one rank only would leave the others inside RCCL: nothing to catch there.)
+            ok = 1
+            try:
+                dn = DistributedNeighList(nl, rank, world, transport="host" if rehearsal else "rccl")
+                nl.Initialize(int(n_total / world * 1.6) + 65536)
+                n_own = dn.scatter(torch.from_numpy(q).to(dev), box, rc)
+                nl.set_capacity(int(n_own * per * 1.3) + 64 * n_own + 4096)
+                dn.build(sync=True)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] nl_make_list_distributed unavailable ({e}); falling back to --dist torch", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                args.dist, dn = "torch(fallback)", None
+                nl = NeighListGPU(rc, *box, dtype=t_dtype, device=dev)
+        if dn is not None:
+            step = lambda: dn.build(sync=False)  # noqa: E731
+            st = None
+        else:
+            st = slab.setup(torch.from_numpy(q).to(dev), None, box, rc, rank, world)
+            nl.Initialize(st.q_all.shape[0])
+            # the default capacity estimate uses the global density with the local count: size it for the slab
+            nl.set_capacity(int(st.n_rows * per * 1.3) + 64 * st.n_rows + 4096)
+            step = lambda: slab.build(nl, st, sync=False)  # noqa: E731
 
     def fence():
         if world > 1:
@@ -383,7 +399,8 @@ def main():
                        "half_pairs_reference": _reference_pairs(ka_key, npairs) if ka_key else None,
                        "offset_bits": info["offset_bits"],
                        "decomposition": "none" if world == 1 else f"{world} z-slabs + 1-cell ghost layers (p2p; "
-                                        + ("nl_make_list_distributed" if args.dist == "cabi" else "torch.distributed around nl_make_list_slab") + ")"},
+                                        + ("nl_make_list_distributed" if args.dist == "cabi" else "torch.distributed around nl_make_list_slab"
+                                           + (" -- FALLBACK: the library's communicator failed" if "fallback" in args.dist else "")) + ")"},
             "roofline": roofline,
         }
         if ka_key:

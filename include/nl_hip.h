@@ -275,7 +275,10 @@ int nl_lj_forces(nl_handle_t h, const void* q_dev, int32_t q_stride, double epsi
 int nl_get_mesh(nl_handle_t h, int32_t mesh[3], int64_t* ncell);
 /* Cell-sorted state of the last build, for tests of the hash/sort stage (a3-a5 of SURVEY.md section 8):
  * cell_start[ncell_local + 1]; sorted positions {x,y,z,id} (16 B for F32, 32 B {double x,y,z; int32 id,row}
- * for F64); sorted_row[n] = input index of each sorted slot. */
+ * for F64); sorted_row[n] = input index of each sorted slot.  After a fine-row build (nl_get_build_info, info[6] != 0)
+ * the cell's particles are additionally ordered by the quarter of the cell they lie in along z and the table has
+ * 4 * ncell_local + 1 entries: entry (cell * 4 + quarter) = first slot of that quarter; every fourth entry is the
+ * cell_start of the plain build. */
 int nl_get_sorted(nl_handle_t h, const int32_t** cell_start_dev, const void** sorted_pos_dev,
                   const int32_t** sorted_row_dev, int64_t* ncell_local);
 /* Diagnostic cycle accumulators of the kernels (filled only when NL_DEBUG_FLAGS & 4 is set in the environment). */
@@ -284,7 +287,9 @@ int nl_debug_occupancy(int32_t out[8]); /* LDS per CU/block (KiB), occupancy API
 /* How the last build was organised: info[0] = 1 when the COUNT sweep kept hit masks and the list was expanded from
  * them (0: two distance sweeps), info[1] = configured sweep variant, info[2] = LDS batch capacity (particles),
  * info[3] = compute units of the device, info[4] = width of the list offsets the build used (32 / 64), info[5] = mask rows per particle (1; up to 7 in a
- * dense build: one per LDS batch of the stencil stream), info[6] = 1 for the half-shell search, info[7] = 0. */
+ * dense build: one per LDS batch of the stencil stream), info[6] = 0, or 1 + c when the build took the fine-row search
+ * (nl_rows.hpp; c = its LDS configuration 0..2) -- the table nl_get_sorted returns is then the fine-row table,
+ * info[7] = 0. */
 int nl_get_build_info(nl_handle_t h, int32_t info[8]);
 int nl_last_error(nl_handle_t h);     /* status of the last failed call on this handle */
 int nl_last_hip_error(nl_handle_t h); /* raw hipError_t behind the last NL_ERR_HIP */

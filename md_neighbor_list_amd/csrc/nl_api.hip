@@ -263,6 +263,8 @@ template <typename T> SweepArgs<T> sweep_args(nl_handle_t h) {
   a.capacity = h->capacity;
   a.status = h->status;
   a.masks = h->masks;
+  // (the two planes of the hit words, one array each inside the same allocation: 128 + 64 bytes per row)
+  a.masks_hi = reinterpret_cast<uint8_t*>(h->masks) + h->masks_bytes / MASK_ROW_BYTES * MASK_LO_BYTES;
   a.isplit = 1;
   a.mask_nb = h->b_mask_nb;
   a.full27_list = h->full27_list;

@@ -730,30 +730,31 @@ template <typename T> struct SweepArgs {
   int32_t* __restrict__ full27_list;       // hand-over list: local cell indices of the cells a kernel leaves to the batched search
   int32_t* __restrict__ full27_count;      // their number (COUNT pass): a meta word next to the status word, zeroed with it
   int32_t* __restrict__ fill_list_count;   // cells the expansion hands to k_fill_list (in full27_list; a meta word of its own)
-  uint32_t* __restrict__ masks;  // [n] rows of 64 x 24 bits (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
+  uint32_t* __restrict__ masks;  // [rows] low plane of the hit words: 64 x 16 bits per row (mask_store/mask_load): bit t of word l of a sorted slot = staged particle t*64+l accepted (COUNT_MASKS -> k_fill_masks)
+  uint8_t* __restrict__ masks_hi;  // [rows] high plane: 64 x 8 bits per row (tiles 16..23; not touched for a stream of <= 16 tiles)
   unsigned long long* dbg_buf;  // diagnostics only: cycle accumulators (dbg & 4)
   int32_t dbg;  // diagnostics only (NL_DEBUG_FLAGS): 1 = skip the search, 2 = skip the staging copy; 0 in production
 };
 
 template <typename T> struct SweepCfg;
-// Hit masks in memory: one row of 64 x 24 bits per sorted slot (a staged stream has at most CAP / 64 = 20 tiles), 192
-// bytes: the low 16 bits of the 64 lanes, then their high 8 bits -- every store and load naturally aligned and
-// consecutive over the lanes.  (Round 2 measurements at cfg 2 / cfg 3: 3-byte words back to back, lane l at byte 3 l,
-// with unaligned accesses: build +0.5 % / +1 %; aligned 256-byte rows, one dword per lane: COUNT -0.5 % / -2 %,
+// Hit masks in memory: a lane keeps one bit per j-tile, at most 24 (a staged stream has at most CAP / 64 = 20 tiles).
+// Two planes, each an array of rows of its own: the low 16 bits of the 64 lanes (128 bytes per row, one cache line) and
+// their high 8 bits (64 bytes per row) -- every store and load naturally aligned and consecutive over the lanes.  A
+// stream of at most 16 tiles (1024 particles: every cell of BASELINE config 3, a quarter of config 2's) has no high
+// bits: its rows of the high plane are neither written nor read (round 3; cfg 3: expansion -8 %, 67 MB less traffic
+// each way).  The condition is a property of the cell (hi_plane_used), the same in the COUNT sweep and the expansion.
+// (Round 2 measurements at cfg 2 / cfg 3, both planes in one 192-byte row: 3-byte words back to back, lane l at byte
+// 3 l, with unaligned accesses: build +0.5 % / +1 %; aligned 256-byte rows, one dword per lane: COUNT -0.5 % / -2 %,
 // expansion +4 % / -5 % -- the expansion is bound by what it reads.)
-constexpr int MASK_ROW_BYTES = 192;
-__device__ __forceinline__ void mask_store(uint32_t* masks, size_t slot, int lane, uint32_t bits) {
-  char* const row = reinterpret_cast<char*>(masks) + slot * MASK_ROW_BYTES;
-  reinterpret_cast<uint16_t*>(row)[lane] = (uint16_t)bits;
-  reinterpret_cast<uint8_t*>(row + 2 * WAVE)[lane] = (uint8_t)(bits >> 16);
+constexpr int MASK_LO_BYTES = 2 * WAVE, MASK_HI_BYTES = WAVE, MASK_ROW_BYTES = MASK_LO_BYTES + MASK_HI_BYTES;  // 192 per row in all
+__device__ __forceinline__ bool hi_plane_used(int32_t mask_nb, int32_t ntiles) { return mask_nb > 1 || ntiles > 16; }
+__device__ __forceinline__ void mask_store(uint32_t* masks, uint8_t* masks_hi, size_t row, int lane, uint32_t bits, bool hi) {
+  reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(masks) + row * MASK_LO_BYTES)[lane] = (uint16_t)bits;
+  if (hi) (masks_hi + row * MASK_HI_BYTES)[lane] = (uint8_t)(bits >> 16);  // (uniform)
 }
-__device__ __forceinline__ void mask_store_at(char* row, int lane, uint32_t bits) {  // row: address of the 192-byte row
-  reinterpret_cast<uint16_t*>(row)[lane] = (uint16_t)bits;
-  reinterpret_cast<uint8_t*>(row + 2 * WAVE)[lane] = (uint8_t)(bits >> 16);
-}
-__device__ __forceinline__ uint32_t mask_load(const uint32_t* masks, size_t slot, int lane) {
-  const char* const row = reinterpret_cast<const char*>(masks) + slot * MASK_ROW_BYTES;
-  return (uint32_t)reinterpret_cast<const uint16_t*>(row)[lane] | (uint32_t)reinterpret_cast<const uint8_t*>(row + 2 * WAVE)[lane] << 16;
+__device__ __forceinline__ uint32_t mask_load(const uint32_t* masks, const uint8_t* masks_hi, size_t row, int lane) {  // both planes
+  return (uint32_t)reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(masks) + row * MASK_LO_BYTES)[lane] |
+         (uint32_t)(masks_hi + row * MASK_HI_BYTES)[lane] << 16;
 }
 template <> struct SweepCfg<float> { static constexpr int CAP = 1280; };   // 20 KB of LDS: 8 workgroups = 32 waves per CU
 template <> struct SweepCfg<double> { static constexpr int CAP = 1280; };  // 40 KB of LDS (registers, not LDS, limit fp64 occupancy)
@@ -1042,15 +1043,20 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(NL_PRIO);
   if constexpr (VBITS) {
     uint32_t w[GC], tot[GC];
-    // the group's rows are mask_nb rows apart: one 64-bit row address, the others at 32-bit multiples of the stride
-    char* const row0 = reinterpret_cast<char*>(a.masks) + ((size_t)slot0 * a.mask_nb + batch) * MASK_ROW_BYTES;
-    const uint32_t row_stride = (uint32_t)a.mask_nb * MASK_ROW_BYTES;
+    // the group's rows are mask_nb rows apart: one 64-bit row address per plane, the others at 32-bit multiples of the stride
+    const size_t mrow0 = (size_t)slot0 * a.mask_nb + batch;
+    char* const lo0 = reinterpret_cast<char*>(a.masks) + mrow0 * MASK_LO_BYTES;
+    uint8_t* const hi0 = a.masks_hi + mrow0 * MASK_HI_BYTES;
+    const bool hi = hi_plane_used(a.mask_nb, ntiles);
 #pragma unroll
     for (int k = 0; k < GC; k++) {
       w[k] = __brev(~bits[k]) >> (32 - ntiles);  // tile t ended at bit ntiles - 1 - t; the bits above were never written
       if (NOSELF && lane == ((self0 + k) & (WAVE - 1))) w[k] &= ~(1u << ((self0 + k) >> 6));
       if (words_out) words_out[k] = w[k];  // (k_sweep_lean_f32: the caller stores the words after the search)
-      else if (store_masks && !(NL_DIAG & 2)) mask_store_at(row0 + k * row_stride, lane, w[k]);
+      else if (store_masks && !(NL_DIAG & 2)) {
+        reinterpret_cast<uint16_t*>(lo0 + (uint32_t)(k * a.mask_nb) * MASK_LO_BYTES)[lane] = (uint16_t)w[k];
+        if (hi) (hi0 + (uint32_t)(k * a.mask_nb) * MASK_HI_BYTES)[lane] = (uint8_t)(w[k] >> 16);
+      }
     }
 #pragma unroll
     for (int k = 0; k < GC; k += 2) {  // two rows per DPP sum: a row has at most CAP < 2^16 accepted partners per batch
@@ -1069,7 +1075,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
       for (int k = 0; k < GC; k++) {
         uint32_t w = __brev(bits[k]) >> (32 - ntiles);
         if (NOSELF && lane == ((self0 + k) & (WAVE - 1))) w &= ~(1u << ((self0 + k) >> 6));
-        mask_store(a.masks, (size_t)(slot0 + k) * a.mask_nb + batch, lane, w);  // mask row of (slot, LDS batch)
+        mask_store(a.masks, a.masks_hi, (size_t)(slot0 + k) * a.mask_nb + batch, lane, w, hi_plane_used(a.mask_nb, ntiles));  // mask row of (slot, LDS batch)
       }
     }
     if (NOSELF) {
@@ -1512,7 +1518,7 @@ template <bool FULL> constexpr int EXPAND_RMAX_OF = FULL ? 192 : 160;
 constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
 
 template <typename T, bool FULL = false, bool PBC = false, typename OFF = int32_t, int RB = 24>
-__global__ void __launch_bounds__(EXPAND_WAVES* WAVE, (sizeof(OFF) == 8 ? 4 : sizeof(T) == 4 ? (FULL ? 7 : 8) : 4)) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(EXPAND_WAVES* WAVE, (sizeof(OFF) == 8 ? 4 : sizeof(T) == 4 ? (FULL || RB > 12 ? 7 : 8) : 4)) __attribute__((amdgpu_num_sgpr(80)))
 k_fill_masks(SweepArgs<T> a) {
   constexpr int CAP = SweepCfg<T>::CAP;
   constexpr int EW = EXPAND_WAVES;
@@ -1560,6 +1566,7 @@ k_fill_masks(SweepArgs<T> a) {
   const int32_t r_beg = min(wave * per_wave, c.ni), r_end = min(r_beg + per_wave, c.ni);
   uint32_t w[RB];
   OFF base_l;  // lane u: list offset of row r0 + u
+  const bool hi_plane = hi_plane_used(1, (c.total_j + WAVE - 1) / WAVE);
   auto load_rows = [&](int32_t r0) {
     {
       // key_pointer[sorted_row[slot]] of the batch's rows, a lane per row: two dependent loads per batch in the shadow
@@ -1568,16 +1575,20 @@ k_fill_masks(SweepArgs<T> a) {
       const int32_t srow = a.sorted_row[c.ibeg + r0 + min(lane, RB - 1)];
       base_l = static_cast<const OFF*>(a.key_pointer)[min((uint32_t)srow, (uint32_t)a.n_rows)];
     }
-    // Consecutive slots are consecutive 192-byte rows: ONE 64-bit base address per batch, the rows at immediate offsets
-    // from it.  Rows past the cell's last one are read as well (the next cells' rows, or the 64 rows of padding behind
+    // Consecutive slots are consecutive rows of each plane: ONE 64-bit base address per plane and batch, the rows at
+    // immediate offsets from it.  Rows past the cell's last one are read as well (the next cells' rows, or the 64 rows of padding behind
     // the last slot) and ignored.  (With `slot = ibeg + min(r0 + u, ni - 1)` per row the compiler spent 17 scalar
     // instructions per row on 64-bit address arithmetic: 400 per wave.)
     const size_t slot0 = (size_t)(c.ibeg + r0);
-    const char* const mrow0 = reinterpret_cast<const char*>(a.masks) + slot0 * MASK_ROW_BYTES;  // (one mask row per slot here)
+    const char* const lo0 = reinterpret_cast<const char*>(a.masks) + slot0 * MASK_LO_BYTES;  // (one mask row per slot here)
+    if (hi_plane) {  // (uniform over the workgroup: a property of the cell)
+      const uint8_t* const hi0 = a.masks_hi + slot0 * MASK_HI_BYTES;
 #pragma unroll
-    for (int u = 0; u < RB; u++) {
-      const char* const row = mrow0 + u * MASK_ROW_BYTES;
-      w[u] = (uint32_t)reinterpret_cast<const uint16_t*>(row)[lane] | (uint32_t)reinterpret_cast<const uint8_t*>(row + 2 * WAVE)[lane] << 16;
+      for (int u = 0; u < RB; u++)
+        w[u] = (uint32_t)reinterpret_cast<const uint16_t*>(lo0 + u * MASK_LO_BYTES)[lane] | (uint32_t)(hi0 + u * MASK_HI_BYTES)[lane] << 16;
+    } else {
+#pragma unroll
+      for (int u = 0; u < RB; u++) w[u] = (uint32_t)reinterpret_cast<const uint16_t*>(lo0 + u * MASK_LO_BYTES)[lane];
     }
   };
   auto base = [&](int u) -> OFF {  // u: compile-time constant after unrolling
@@ -1774,7 +1785,7 @@ __global__ void __launch_bounds__(FD_WAVES* WAVE) k_fill_dense(SweepArgs<T> a, c
       const int32_t slot = c.ibeg + min(r0 + u * FD_WAVES, c.ni - 1);
       base[u] = base_sorted[slot];
 #pragma unroll
-      for (int b = 0; b < FD_NB; b++) w[u][b] = mask_load(a.masks, (size_t)slot * nb + min(b, nb - 1), lane);
+      for (int b = 0; b < FD_NB; b++) w[u][b] = mask_load(a.masks, a.masks_hi, (size_t)slot * nb + min(b, nb - 1), lane);
     }
 #pragma unroll
     for (int u = 0; u < FD_RB; u++)

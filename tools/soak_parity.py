@@ -18,6 +18,7 @@ from tests.util import canonical_csr  # noqa: E402
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 bad = 0
+paths = {}
 for case in range(cases):
     dtype = np.float32 if rng.random() < 0.6 else np.float64
     os.environ["NL_SWEEP_VARIANT"] = os.environ.get("SOAK_VARIANT") or str(rng.choice([1, 3, 3]))
@@ -72,7 +73,10 @@ for case in range(cases):
             bad += 1
             print(f"MISMATCH case {case} rep {rep}: n={n} box={box} rc={rc} dtype={dtype.__name__} full={full} "
                   f"pbc={pbc} variant={os.environ['NL_SWEEP_VARIANT']} width={os.environ['NL_OFFSET_WIDTH']} binning={os.environ['NL_BINNING']} rows={rows} info={nl.build_info()}", flush=True)
+    info = nl.build_info()
+    key = f"rows{info['fine_rows']}" if info["fine_rows"] else ("masks" + ("x" if info["mask_rows"] > 1 else "") if info["masks"] else "two sweeps")
+    paths[key] = paths.get(key, 0) + 1
     if case % 50 == 49:
         print(f"{case + 1} cases, {bad} mismatches", flush=True)
-print(f"soak done: {cases} cases, {bad} mismatches")
+print(f"soak done: {cases} cases, {bad} mismatches; search paths taken: {dict(sorted(paths.items()))}")
 sys.exit(1 if bad else 0)
