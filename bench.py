@@ -190,7 +190,7 @@ def _stage_table(stages, info, n, p, vec_bytes, pos_bytes, full=False):
     add("binning 2+3 (k_bin_scatter, k_bin_cells)", "reorder", vec_bytes * n + 2 * (pos_bytes + 4) * n + (pos_bytes + 8) * n,
         "positions read; row-grouped copy written and read; sorted positions + row + id written")
     add("pair search COUNT" + (" keeping hit masks" if info["masks"] else ""), "count", (pos_bytes + 4) * n + 4 * n + masks,
-        "sorted positions + rows read once, counts" + (f" and {192 * nb} B of hit masks per particle" if info["masks"] else "") + " written")
+        "sorted positions + rows read once, counts" + (f" and up to {192 * nb} B of hit masks per particle (128 B where the stream has at most 16 tiles)" if info["masks"] else "") + " written")
     add("row scan (k_scan_chained)", "row_scan", 4 * n + 4 * n, "counts read, key_pointer written")
     if info["masks"]:
         if nb > 1:
