@@ -793,7 +793,7 @@ template <typename T> struct TileOf<T, true> { typedef PosS type; };
 #ifndef NL_STAMP_FILL  // the same for the expansion kernels (tools/fill_phases.py); not together with NL_STAMP
 #define NL_STAMP_FILL 0
 #endif
-#ifndef NL_DIAG  // wrong lists, timing only: 1 = no tile tests, 2 = no mask stores, 4 = no staging loads
+#ifndef NL_DIAG  // wrong lists, timing only: 1 = no tile tests, 2 = no mask stores, 4 = no staging loads, 16 = gathered tiles
 #define NL_DIAG 0
 #endif
 constexpr int NL_PRIO = 3;  // wave priority outside the tile loop of the COUNT_MASKS sweeps
@@ -1030,6 +1030,25 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
   // gid_j > gid_i, and their position 1e18 is never in range), so tiles need no per-lane tail handling.  Two register sets in ping-pong: the ds_read of the
   // next tile is in flight while the current one is tested, and no register copies are needed.
   const int32_t last = (ntiles - 1) * WAVE + lane;
+#if NL_DIAG & 16
+  // Timing experiment (wrong lists, right counts): the tile is GATHERED -- lane l of tile t reads slot P(64 t + l), P =
+  // the stream's runs of 24 consecutive slots in reverse order (a bijection): what a search over a candidate list of
+  // sub-cell runs would do to the LDS read (per-lane addresses, bank conflicts) and to the instruction count.
+  const int32_t g_runs = ntiles * WAVE / 24;
+  auto gat = [&](int32_t s) {
+    const int32_t r = (int32_t)__umulhi((uint32_t)s, 178956971u);  // s / 24 for s < 2^16
+    return r < g_runs ? (g_runs - 1 - r) * 24 + (s - r * 24) : s;
+  };
+  TileT pa = tile[gat(lane)], pb;
+  int32_t t = 0;
+  if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(0);
+  for (; t + 1 < ntiles; t += 2) {
+    pb = tile[gat((t + 1) * WAVE + lane)];
+    test_tile(pa, t);
+    pa = tile[gat(min((t + 2) * WAVE + lane, last))];
+    test_tile(pb, t + 1);
+  }
+#else
   TileT pa = tile[lane], pb;
   int32_t t = (NL_DIAG & 1) ? ntiles : 0;
   if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(0);  // the tile loop yields to waves that are setting up, staging, storing
@@ -1039,6 +1058,7 @@ __device__ __forceinline__ int32_t search_group(const SweepArgs<T>& a, const typ
     pa = tile[min((t + 2) * WAVE + lane, last)];
     test_tile(pb, t + 1);
   }
+#endif
   if (t < ntiles) test_tile(pa, t);
   if (MODE == MODE_COUNT_MASKS) __builtin_amdgcn_s_setprio(NL_PRIO);
   if constexpr (VBITS) {
