@@ -289,7 +289,8 @@ int nl_debug_occupancy(int32_t out[8]); /* LDS per CU/block (KiB), occupancy API
  * info[3] = compute units of the device, info[4] = width of the list offsets the build used (32 / 64), info[5] = mask rows per particle (1; up to 7 in a
  * dense build: one per LDS batch of the stencil stream), info[6] = 0, or 1 + c when the build took the fine-row search
  * (nl_rows.hpp; c = its LDS configuration 0..2) -- the table nl_get_sorted returns is then the fine-row table,
- * info[7] = 0. */
+ * info[7] = 1 when the build used the small instances of the COUNT sweep and the expansion (sparse boxes: 2 waves /
+ * 1 wave per cell, half the LDS buffer), else 0. */
 int nl_get_build_info(nl_handle_t h, int32_t info[8]);
 int nl_last_error(nl_handle_t h);     /* status of the last failed call on this handle */
 int nl_last_hip_error(nl_handle_t h); /* raw hipError_t behind the last NL_ERR_HIP */

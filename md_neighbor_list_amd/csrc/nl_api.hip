@@ -78,6 +78,9 @@ struct nl_handle_s {
   int rows_env = -1;               // NL_ROWS: -1 (default) = the fine-row search where the 27-cell path would need several LDS batches
                                    // per cell (denser than 40.3 particles per cell), 0 = never, 1..3 = RowsCfg<V - 1> wherever a
                                    // build qualifies (tests), 4 = wherever a build qualifies, RowsCfg by density (sweeps)
+  bool b_lean_small = false;       // this build: the 2-wave, half-buffer instance of k_sweep_lean_f32 (sparse boxes)
+  int lean_small_env = 1;          // NL_LEAN_SMALL=0: never (same-box A/B)
+  int fill_small_env = 1;          // NL_FILL_SMALL=0: the 2-wave expansion also in sparse boxes (same-box A/B)
   bool b_rows = false;             // this build: fine rows (k_bin_cells<FINE>, k_sweep_rows_f32, k_fill_rows); the cell table is
   int b_rows_v = 0;                // fine_start (4 M + 1 entries); RowsCfg of the build
   bool dense_masks_off = false;    // NL_DENSE_MASKS=0: dense builds use two distance sweeps (the round-1 path)
@@ -332,6 +335,13 @@ template <typename T, bool FULL, bool PBC, typename OFF> void launch_fill_masks(
   }
   // rows a wave loads up front: 24, or 12 where cells hold ~20 particles or fewer (a wave then has ~10 rows)
   const bool few_rows = (double)h->n <= 21.0 * (double)std::max<int64_t>(1, h->ncell_local);
+  if constexpr (sizeof(T) == 4 && !PBC) {
+    if (h->b_lean_small && h->fill_small_env) {  // sparse boxes: a wave per cell (its ~19 rows in one batch), ids of half a stream
+      hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF, 24, 1, SweepCfg<T>::CAP / 2>), dim3(ncells_i), dim3(WAVE), 0, s, a);
+      hipLaunchKernelGGL((k_fill_list<T, FULL, PBC>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+      return;
+    }
+  }
   if (few_rows)
     hipLaunchKernelGGL((k_fill_masks<T, FULL, PBC, OFF, 12>), dim3(ncells_i), dim3(EXPAND_WAVES * WAVE), 0, s, a);
   else
@@ -357,7 +367,8 @@ template <typename T, bool FULL, bool PBC> void launch_sweep_kind(nl_handle_t h,
       if constexpr (sizeof(T) == 4) {
         if (!PBC && h->b_mask_nb == 1) {
           // a workgroup per cell, single-batch cells only; the others go on the hand-over list of the batched search
-          hipLaunchKernelGGL((k_sweep_lean_f32<FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
+          if (h->b_lean_small) hipLaunchKernelGGL((k_sweep_lean_f32<FULL, 2, LEAN_SMALL_CAP>), dim3(ncells_i), dim3(2 * WAVE), 0, s, a);
+          else hipLaunchKernelGGL((k_sweep_lean_f32<FULL>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), 0, s, a);
           hipLaunchKernelGGL((k_sweep_list_f32<FULL>), dim3(2 * h->num_cus), dim3(SWEEP_WAVES * WAVE), 0, s, a);
         } else {
           hipLaunchKernelGGL((k_sweep_count_masks_f32<FULL, PBC>), dim3(ncells_i), dim3(SWEEP_WAVES * WAVE), h->dbg_lds_pad, s, a);
@@ -445,6 +456,9 @@ void set_build_state(nl_handle_t h, const void* q_dev, int32_t stride, const int
   const bool sparse_enough = mean_stream <= 0.85 * SweepCfg<T>::CAP;  // mean stencil <= 1088: <= 40.3 per cell
   h->b_use_masks = h->b_variant >= 3 && sparse_enough && mask_rows_ready(h, 1);
   h->b_mask_nb = 1;
+  // sparse boxes (mean stream + 5 sigma within half the LDS buffer: up to 19.6 particles per cell): the 2-wave instance
+  // of the lean COUNT sweep; a cell beyond it goes to the batched search like any other that does not fit
+  h->b_lean_small = h->lean_small_env != 0 && mean_stream + 5.0 * std::sqrt(mean_stream) <= (double)LEAN_SMALL_CAP;
   // The fine-row search (nl_rows.hpp): fp32, open box, the two-level binning, and a cell edge that exceeds the cut-off
   // along z by more than the rounding of the cell hash can hide (rows_margin_ok).  RowsCfg by the mean stencil
   // stream m = 27 <N/cell>: m + 5 sigma within the LDS buffer, the piece a wave walks + 6 sigma within its hit word.
@@ -844,6 +858,8 @@ int nl_create(nl_handle_t* out, int dtype, double rc, double Lx, double Ly, doub
     if (const char* v = getenv("NL_ISPLIT")) h->isplit_env = std::max(0, atoi(v));
     if (const char* v = getenv("NL_DENSE_MASKS")) h->dense_masks_off = atoi(v) == 0;
     if (const char* v = getenv("NL_ROWS")) h->rows_env = std::max(-1, std::min(atoi(v), 4));
+    if (const char* v = getenv("NL_LEAN_SMALL")) h->lean_small_env = atoi(v) != 0;
+    if (const char* v = getenv("NL_FILL_SMALL")) h->fill_small_env = atoi(v) != 0;
     if (const char* v = getenv("NL_OFFSET_WIDTH")) h->offset_width = atoi(v) == 64 ? 64 : atoi(v) == 32 ? 32 : 0;
     if (const char* v = getenv("NL_BINNING")) h->bin_two_level = atoi(v) != 1;
     if (const char* v = getenv("NL_GRAPH")) h->use_graph = atoi(v) != 0;
@@ -1271,6 +1287,7 @@ int nl_get_build_info(nl_handle_t h, int32_t info[8]) {
   info[4] = h->b_wide ? 64 : 32;
   info[5] = h->b_mask_nb;
   info[6] = h->b_rows ? 1 + h->b_rows_v : 0;  // fine-row search: the cell table of nl_get_sorted is the fine-row table
+  info[7] = h->b_use_masks && !h->b_rows && h->b_mask_nb == 1 && h->dtype == NL_F32 && !h->b_pbc && h->b_lean_small ? 1 : 0;
   info[0] = h->b_use_masks ? 1 : 0;
   info[1] = h->sweep_variant;
   info[2] = h->dtype == NL_F32 ? SweepCfg<float>::CAP : SweepCfg<double>::CAP;

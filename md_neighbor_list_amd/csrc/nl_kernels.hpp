@@ -1537,11 +1537,12 @@ __device__ __forceinline__ int32_t scan64_dpp(int32_t v) {  // inclusive scan ov
 template <bool FULL> constexpr int EXPAND_RMAX_OF = FULL ? 192 : 160;
 constexpr int EXPAND_WAVES = 2;  // waves per workgroup of k_fill_masks: 16 workgroups (cells) in flight per CU
 
-template <typename T, bool FULL = false, bool PBC = false, typename OFF = int32_t, int RB = 24>
-__global__ void __launch_bounds__(EXPAND_WAVES* WAVE, (sizeof(OFF) == 8 ? 4 : sizeof(T) == 4 ? (FULL || RB > 12 ? 7 : 8) : 4)) __attribute__((amdgpu_num_sgpr(80)))
+// EW, CAP: 2 waves and room for the ids of a full stream, or (sparse boxes, as k_sweep_lean_f32's small instance) one
+// wave per cell and half of it: half as many cell tables and id stagings, no barrier between waves (cfg 3: build -2.5 %).
+// (One wave per cell with 40 rows up front at cfg 2: 96 VGPRs, 5 waves per SIMD, expansion 0.207 against 0.175 ms.)
+template <typename T, bool FULL = false, bool PBC = false, typename OFF = int32_t, int RB = 24, int EW = EXPAND_WAVES, int CAP = SweepCfg<T>::CAP>
+__global__ void __launch_bounds__(EW* WAVE, (sizeof(OFF) == 8 ? 4 : sizeof(T) == 4 ? (FULL || RB > 12 ? 7 : 8) : 4)) __attribute__((amdgpu_num_sgpr(80)))
 k_fill_masks(SweepArgs<T> a) {
-  constexpr int CAP = SweepCfg<T>::CAP;
-  constexpr int EW = EXPAND_WAVES;
   constexpr int EXPAND_RMAX = EXPAND_RMAX_OF<FULL>;
   // One LDS array (a second __shared__ object next to an LDS-DMA target makes hipcc drain the DMA before every
   // ds_read): the ids of the stencil stream (4.5 KiB) + per wave four rows being put together.

@@ -103,9 +103,13 @@ __device__ __forceinline__ void pipe_search(const SweepArgs<float>& a, const Cel
 // One workgroup per cell, like k_sweep_count_masks_f32, but only what a single-batch cell needs: the stream by LDS-DMA,
 // the groups' i-particles taken from the staged stream (no loads of their own), no batch loop, no progress words; a
 // cell whose stream does not fit goes on the list of k_sweep_list_f32.  (NL_PIPE=1.)
-template <bool FULL>
-__global__ void __launch_bounds__(SWEEP_WAVES* WAVE, 8) __attribute__((amdgpu_num_sgpr(80))) k_sweep_lean_f32(SweepArgs<float> a) {
-  constexpr int CAP = SweepCfg<float>::CAP, NW = SWEEP_WAVES;
+// NW, CAP: 4 waves and the full buffer (20 KB: 8 workgroups = 32 waves per CU), or -- boxes whose streams stay below
+// half of it: BASELINE config 3 -- 2 waves and half the buffer (10 KB: 16 workgroups = 32 waves per CU): the same
+// number of group passes per cell by half as many waves, i.e. half as many cell tables, barriers and flushes (what a
+// wave does besides searching is half of its life when its search is one pass of 9 tiles).
+constexpr int LEAN_SMALL_CAP = SweepCfg<float>::CAP / 2;
+template <bool FULL, int NW = SWEEP_WAVES, int CAP = SweepCfg<float>::CAP>
+__global__ void __launch_bounds__(NW* WAVE, 8) __attribute__((amdgpu_num_sgpr(80))) k_sweep_lean_f32(SweepArgs<float> a) {
   __shared__ __attribute__((aligned(32))) Pos<float> buf[CAP];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_amdgcn_s_setprio(NL_PRIO);  // everything but the tile loop of search_group

@@ -325,7 +325,8 @@ class NeighListGPU:
         info = (C.c_int32 * 8)()
         check(self._lib.nl_get_build_info(self._h, C.byref(info)), "nl_get_build_info")
         return {"masks": bool(info[0]), "variant": int(info[1]), "lds_batch": int(info[2]), "cus": int(info[3]),
-                "offset_bits": int(info[4]), "mask_rows": int(info[5]), "fine_rows": int(info[6])}
+                "offset_bits": int(info[4]), "mask_rows": int(info[5]), "fine_rows": int(info[6]),
+                "small_cells": int(info[7])}
 
     def profile_last_build(self, reps=10):
         """Same for the last build (also a slab build); its position/id tensors are kept alive by this object."""

@@ -1035,7 +1035,10 @@ def test_cells_handed_to_the_batched_search():
 
     rng = np.random.default_rng(5)
     cases = [(50000, (36.84, 36.84, 36.84), 3.3, 0.0), (9000, (25.0, 14.0, 19.0), 3.1, 0.0), (4096, (16.0, 16.0, 16.0), 3.3, 0.0),
-             (60000, (40.0, 40.0, 40.0), 3.3, 0.12), (120000, (50.0, 60.0, 45.0), 3.0, 0.02)]
+             (60000, (40.0, 40.0, 40.0), 3.3, 0.12), (120000, (50.0, 60.0, 45.0), 3.0, 0.02),
+             # sparse boxes: the small instances of the COUNT sweep and the expansion (half the LDS buffer), plain and with
+             # a cluster whose cells exceed half the buffer (hand-over with masks) and the whole buffer (re-search)
+             (20000, (50.0, 50.0, 50.0), 3.3, 0.0), (40000, (50.0, 60.0, 45.0), 3.0, 0.03), (60000, (50.0, 60.0, 45.0), 3.0, 0.008)]
     for n, box, rc, clustered in cases:
         q, box = inputs.uniform_box(n, dtype=np.float32, seed=int(rng.integers(1 << 30)), box=box)
         if clustered:  # part of the particles into two cells' worth of volume: streams of several LDS batches there
@@ -1043,6 +1046,7 @@ def test_cells_handed_to_the_batched_search():
             q[:k, :3] = (np.array(box) * 0.5 + rng.uniform(-0.9 * rc, 0.9 * rc, size=(k, 3))).astype(np.float32)
         ref = _po().build(q, rc, box)
         nl, nop, kp, sl = gpu_build(q, rc, box)
+        assert nl.build_info()["small_cells"] == (1 if n / (int(box[0] / rc) * int(box[1] / rc) * int(box[2] / rc)) < 15 else 0), nl.build_info()
         assert int(kp[-1]) == ref.npairs, (n, clustered)
         assert np.array_equal(nop, ref.number_of_partners), (n, clustered)
         assert np.array_equal(canonical_csr(kp, sl), ref.canonical().sorted_list), (n, clustered)
