@@ -748,9 +748,27 @@ template <typename T> struct SweepCfg;
 // expansion +4 % / -5 % -- the expansion is bound by what it reads.)
 constexpr int MASK_LO_BYTES = 2 * WAVE, MASK_HI_BYTES = WAVE, MASK_ROW_BYTES = MASK_LO_BYTES + MASK_HI_BYTES;  // 192 per row in all
 __device__ __forceinline__ bool hi_plane_used(int32_t mask_nb, int32_t ntiles) { return mask_nb > 1 || ntiles > 16; }
+// NT: non-temporal stores -- the rows are read once, by the expansion, after 200 MB more of them have been written: the
+// 4-wave COUNT sweep keeps them out of the L2's way (cfg 2: build -1.2 %; the sparse-box instances are 1.7 % slower with
+// them -- their 128 MB of rows are still in the last-level cache when the expansion comes -- and keep plain stores).
+template <bool NT = false>
 __device__ __forceinline__ void mask_store(uint32_t* masks, uint8_t* masks_hi, size_t row, int lane, uint32_t bits, bool hi) {
-  reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(masks) + row * MASK_LO_BYTES)[lane] = (uint16_t)bits;
-  if (hi) (masks_hi + row * MASK_HI_BYTES)[lane] = (uint8_t)(bits >> 16);  // (uniform)
+  uint16_t* const lo_p = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(masks) + row * MASK_LO_BYTES) + lane;
+  uint8_t* const hi_p = masks_hi + row * MASK_HI_BYTES + lane;
+  if constexpr (NT) {
+    __builtin_nontemporal_store((uint16_t)bits, lo_p);
+    if (hi) __builtin_nontemporal_store((uint8_t)(bits >> 16), hi_p);  // (uniform)
+  } else {
+    *lo_p = (uint16_t)bits;
+    if (hi) *hi_p = (uint8_t)(bits >> 16);  // (uniform)
+  }
+}
+// The expansion reads every mask row once: in the 2-wave instances as non-temporal loads, which leaves the L2 to the ids
+// and list offsets the kernel reads 27 times / at random (cfg 2: expansion 0.181 -> 0.174 ms; the 1-wave instance of
+// sparse boxes is 4 % slower with them and keeps plain loads).
+template <bool NT, typename P> __device__ __forceinline__ P mask_ld(const P* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
 }
 __device__ __forceinline__ uint32_t mask_load(const uint32_t* masks, const uint8_t* masks_hi, size_t row, int lane) {  // both planes
   return (uint32_t)reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(masks) + row * MASK_LO_BYTES)[lane] |
@@ -1606,10 +1624,10 @@ k_fill_masks(SweepArgs<T> a) {
       const uint8_t* const hi0 = a.masks_hi + slot0 * MASK_HI_BYTES;
 #pragma unroll
       for (int u = 0; u < RB; u++)
-        w[u] = (uint32_t)reinterpret_cast<const uint16_t*>(lo0 + u * MASK_LO_BYTES)[lane] | (uint32_t)(hi0 + u * MASK_HI_BYTES)[lane] << 16;
+        w[u] = (uint32_t)mask_ld<EW == 2>(reinterpret_cast<const uint16_t*>(lo0 + u * MASK_LO_BYTES) + lane) | (uint32_t)mask_ld<EW == 2>(hi0 + u * MASK_HI_BYTES + lane) << 16;
     } else {
 #pragma unroll
-      for (int u = 0; u < RB; u++) w[u] = (uint32_t)reinterpret_cast<const uint16_t*>(lo0 + u * MASK_LO_BYTES)[lane];
+      for (int u = 0; u < RB; u++) w[u] = (uint32_t)mask_ld<EW == 2>(reinterpret_cast<const uint16_t*>(lo0 + u * MASK_LO_BYTES) + lane);
     }
   };
   auto base = [&](int u) -> OFF {  // u: compile-time constant after unrolling

@@ -40,6 +40,7 @@ struct PipePending {
   int32_t mine, row_l, slot0, gcount;  // gcount == 0: nothing pending
 };
 
+template <bool NT>
 __device__ __forceinline__ void pipe_flush(const SweepArgs<float>& a, PipePending& p, int lane, bool hi) {
   if (p.gcount <= 0) return;  // uniform
   // (the count first: its row index is the one load this waits for, and a wait placed behind the mask stores would be
@@ -47,7 +48,7 @@ __device__ __forceinline__ void pipe_flush(const SweepArgs<float>& a, PipePendin
   if (lane < p.gcount) a.count[p.row_l] = p.mine;
 #pragma unroll
   for (int k = 0; k < PIPE_G; k++)
-    if (k < p.gcount) mask_store(a.masks, a.masks_hi, (size_t)(p.slot0 + k) * a.mask_nb, lane, p.w[k], hi);
+    if (k < p.gcount) mask_store<NT>(a.masks, a.masks_hi, (size_t)(p.slot0 + k) * a.mask_nb, lane, p.w[k], hi);
   p.gcount = 0;
 }
 
@@ -81,7 +82,7 @@ __device__ __forceinline__ void pipe_search(const SweepArgs<float>& a, const Cel
     const int32_t i0 = g * gbase + min(g, grem);
     const int32_t gcount = gbase + (g < grem ? 1 : 0);  // wave-uniform
     if (gcount <= 0) break;
-    pipe_flush(a, p, lane, hi_plane_used(a.mask_nb, ntiles));  // (a wave with several groups: the previous one's words go out before the next search)
+    pipe_flush<NW == SWEEP_WAVES>(a, p, lane, hi_plane_used(a.mask_nb, ntiles));  // (a wave with several groups: the previous one's words go out before the next search)
     const int32_t k = min(lane, gcount - 1);
     Pos<float> pi_l = tile[own + i0 + k];  // the group's i-particles come from the staged stream, not from memory
     const int32_t row_l = a.sorted_row[ibeg + i0 + k];
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(NW* WAVE, 8) __attribute__((amdgpu_num_sgpr(80
   PipePending pend;
   pend.gcount = 0, pend.mine = 0, pend.row_l = 0, pend.slot0 = 0;
   pipe_search<FULL, NW>(a, c, buf, lane, wave, pend);
-  pipe_flush(a, pend, lane, hi_plane_used(a.mask_nb, (c.total_j + WAVE - 1) / WAVE));
+  pipe_flush<NW == SWEEP_WAVES>(a, pend, lane, hi_plane_used(a.mask_nb, (c.total_j + WAVE - 1) / WAVE));
 }
 
 // The cells k_sweep_pipe_f32 left out (local cell indices in full27_list): the batched search, a workgroup per cell.
