@@ -528,8 +528,12 @@ int enqueue_build(nl_handle_t h, const void* q_dev, int32_t stride, const int32_
       if (events) (void)hipEventRecord(ev[NL_STAGE_CELL_SCAN], s);
       // (no scan launch: every block of k_bin_scatter scans the row totals itself and block 0 publishes the row starts)
       if (events) (void)hipEventRecord(ev[NL_STAGE_REORDER], s);
-      hipLaunchKernelGGL((k_bin_scatter<T>), dim3(blocks), dim3(BIN_THREADS), 0, s, q, stride, gid, n, h->bin_chunk, g, nrows,
-                         rc_arr, rs_arr, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row, h->status, ph);
+      if (h->bin_chunk >= 8 * BIN_THREADS)
+        hipLaunchKernelGGL((k_bin_scatter<T, 8>), dim3(blocks), dim3(BIN_THREADS), 0, s, q, stride, gid, n, h->bin_chunk, g, nrows,
+                           rc_arr, rs_arr, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row, h->status, ph);
+      else
+        hipLaunchKernelGGL((k_bin_scatter<T, 4>), dim3(blocks), dim3(BIN_THREADS), 0, s, q, stride, gid, n, h->bin_chunk, g, nrows,
+                           rc_arr, rs_arr, h->blk_base, static_cast<Pos<T>*>(h->tmp_pos), h->tmp_row, h->status, ph);
       if constexpr (sizeof(T) == 4) {
         if (h->b_rows) {
           hipLaunchKernelGGL((k_bin_cells<T, true>), dim3(cells_grid), dim3(256), 0, s, g, nrows, rs_arr,

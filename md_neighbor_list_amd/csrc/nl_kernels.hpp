@@ -468,7 +468,10 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_rows(const T* __restrict__ 
   }
 }
 
-template <typename T>
+// UNROLL: particles per thread whose loads are in flight together: 8 where a chunk is 8 particles per thread (one round
+// trip per chunk: binning 2 + 3 at cfg 2 41.6 -> 38.1 us), 4 for the smaller chunks of small boxes.  (k_bin_rows is
+// 1 us slower with 8.)
+template <typename T, int UNROLL = BIN_UNROLL>
 __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict__ q, int32_t stride,
                                                              const int32_t* __restrict__ gid, int32_t n, int32_t chunk,
                                                              Grid<T> g, int32_t nrows, const int32_t* __restrict__ row_count,
@@ -513,14 +516,14 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
   const int32_t i_end = ph.dyn ? min(ph.i_end, g.n_rows + ph.dyn[0] + ph.dyn[1]) : ph.i_end;
   const int32_t beg = ph.i_beg + blockIdx.x * chunk, end = min(beg + chunk, i_end);
   const bool gid_in_w = gid == reinterpret_cast<const int32_t*>(1);  // NL_GID_IN_W: the id travels in the w component
-  for (int32_t i0 = beg + tid; i0 < end; i0 += BIN_UNROLL * BIN_THREADS) {  // all loads of a trip first (see k_bin_rows)
-    T x[BIN_UNROLL], y[BIN_UNROLL], z[BIN_UNROLL];
-    int32_t id[BIN_UNROLL];
+  for (int32_t i0 = beg + tid; i0 < end; i0 += UNROLL * BIN_THREADS) {  // all loads of a trip first (see k_bin_rows)
+    T x[UNROLL], y[UNROLL], z[UNROLL];
+    int32_t id[UNROLL];
     // three loops, one per id source, each free of branches between its loads: a load under a branch is waited for at
     // the join (one memory round trip per particle instead of one per trip)
     if (gid_in_w) {
 #pragma unroll
-      for (int u = 0; u < BIN_UNROLL; u++) {
+      for (int u = 0; u < UNROLL; u++) {
         const int32_t i = min(i0 + u * BIN_THREADS, end - 1);
         load_xyz(q, stride, i, x[u], y[u], z[u]);
         if constexpr (sizeof(T) == 4) id[u] = __float_as_int(q[(size_t)i * 4 + 3]);
@@ -528,14 +531,14 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
       }
     } else if (gid) {
 #pragma unroll
-      for (int u = 0; u < BIN_UNROLL; u++) {
+      for (int u = 0; u < UNROLL; u++) {
         const int32_t i = min(i0 + u * BIN_THREADS, end - 1);
         load_xyz(q, stride, i, x[u], y[u], z[u]);
         id[u] = gid[i];
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < BIN_UNROLL; u++) {
+      for (int u = 0; u < UNROLL; u++) {
         const int32_t i = min(i0 + u * BIN_THREADS, end - 1);
         load_xyz(q, stride, i, x[u], y[u], z[u]);
         id[u] = i;
@@ -543,10 +546,10 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_scatter(const T* __restrict
     }
     if (!(g.dbg & 512)) {
 #pragma unroll
-      for (int u = 0; u < BIN_UNROLL; u++) keep_in_flight(x[u]), keep_in_flight(y[u]), keep_in_flight(z[u]), keep_in_flight(id[u]);
+      for (int u = 0; u < UNROLL; u++) keep_in_flight(x[u]), keep_in_flight(y[u]), keep_in_flight(z[u]), keep_in_flight(id[u]);
     }
 #pragma unroll
-    for (int u = 0; u < BIN_UNROLL; u++) {
+    for (int u = 0; u < UNROLL; u++) {
       const int32_t i = i0 + u * BIN_THREADS;
       if (i >= end) break;
       int32_t lz = 0, row = 0;
