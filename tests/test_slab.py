@@ -61,6 +61,7 @@ def test_slab_union_equals_global_list_gpu(world, case):
     (2, (60000, (30.0, 30.0, 66.0), 3.3, "float32", 83)),
     (3, (50000, (25.0, 25.0, 80.0), 3.3, "float64", 84)),
     (3, (40000, (25.0, 25.0, 80.0), 3.3, "float32", 85, [7, 8])),  # two empty layers: a rank with nothing to send upwards
+    (5, (90000, (25.0, 25.0, 120.0), 3.3, "float32", 301)),  # interior ranks with four distinct neighbours' messages in flight
 ])
 def test_distributed_build_behind_the_c_abi_with_moving_particles(world, case):
     """nl_comm_create_callbacks + nl_make_list_distributed: the pack kernel, the count and halo
