@@ -245,6 +245,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        # A watchdog for the multi-rank run: the N > 1 exchange over RCCL has never run on hardware;
+        # should a rank ever wait for a message that does not come, the job ends with an error after NL_BENCH_WATCHDOG_S
+        # seconds (default 600) instead of holding the node until the driver's limit.
+        import signal
+
+        def _watchdog(signum, frame):
+            sys.stderr.write(f"[rank {rank}] bench.py watchdog: no result after the time limit -- a rank is stuck in the halo exchange\n")
+            sys.stderr.flush()
+            os._exit(124)
+
+        signal.signal(signal.SIGALRM, _watchdog)
+        signal.alarm(int(os.environ.get("NL_BENCH_WATCHDOG_S", "600")))
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -459,6 +471,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(q, box, rc)
         print(json.dumps(out), flush=True)
     if world > 1:
+        signal.alarm(0)
         dist.barrier()
         dist.destroy_process_group()
 
